@@ -1,0 +1,287 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (needs /root/reference and transformers):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What it executes (nothing from the reference is copied into this repo; the .npz
+files hold inputs, seeded random-init weights and the reference's outputs):
+
+* ``/root/reference/src/models/clipcap.py`` - ``MLP``, ``TransformerMapper``,
+  ``ClipCaptionPrefix.forward`` / ``.generate`` on locally saved random-init
+  ``GPT2LMHeadModel`` (eager attention), via the import shim SURVEY.md 8(c)
+  describes (``transformers.AdamW`` no longer exists in transformers 5.x).
+* the same reference ``forward``/``generate`` code driving an HF ``OPTForCausalLM``
+  (the reference hard-wires GPT-2, SURVEY F4: the OPT fixture swaps ``model.gpt``
+  for the OPT model and aliases ``.transformer.wte`` so the reference's own
+  concat/label/greedy code runs unchanged).
+* ``/root/reference/src/models/vct0.py`` ``VCT0Model.insert_prefix_into_input``
+  (called unbound with a namespace ``self``; it only reads ``prefix_length`` and
+  ``lm_embedding_size``) on the two cases of ``src/models/vct0_test.py`` and one
+  4-shot case.
+* HF ``CLIPVisionModelWithProjection`` (quick_gelu) as the stand-in for OpenAI CLIP's
+  ``encode_image`` (the ``clip`` package is absent and un-pinned).
+
+Known-answer tables that need no execution (label masking, restated from
+``src/trainers/clipcap_exector.py:134-150`` because the executor module cannot be
+imported here) are written from hand-derived expectations.
+"""
+import os
+import sys
+import tempfile
+import types
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")
+
+import numpy as np
+import torch
+import transformers
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/src/models"
+
+
+def _import_reference():
+    # shim 1: symbol imported by the reference, never used.  transformers 5.x swaps its lazy
+    # module object in sys.modules while resolving names, so re-apply before each import.
+    sys.modules["transformers"].AdamW = torch.optim.AdamW
+    stub = types.ModuleType("flamingo_pytorch")  # shim 2: only mapping_type="perceiver" needs it
+    stub.PerceiverResampler = type("PerceiverResampler", (torch.nn.Module,), {})
+    sys.modules.setdefault("flamingo_pytorch", stub)
+    sys.path.insert(0, REF)
+    import clipcap  # noqa
+    sys.modules["transformers"].AdamW = torch.optim.AdamW
+    import vct0  # noqa
+    return clipcap, vct0
+
+
+def _np(sd, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path)/1024:.1f} KiB, {len(arrays)} arrays")
+
+
+def ragged_batch(gen, B, T, V, pad_id, min_len):
+    lens = torch.randint(min_len, T + 1, (B,), generator=gen)
+    lens[0] = T
+    ids = torch.randint(0, V - 2, (B, T), generator=gen)
+    mask = (torch.arange(T)[None] < lens[:, None]).long()
+    ids = ids * mask + pad_id * (1 - mask)
+    return ids, mask
+
+
+def main():
+    clipcap, vct0 = _import_reference()
+    from transformers import (CLIPVisionConfig, CLIPVisionModelWithProjection, GPT2Config, GPT2LMHeadModel,
+                              OPTConfig, OPTForCausalLM)
+
+    tmp = tempfile.mkdtemp(prefix="eavqa_golden_")
+    gen = torch.Generator().manual_seed(2021)  # reference seed, configs/vqa2/clip_cap.jsonnet:17
+
+    # ------------------------------------------------------------------ mappers
+    torch.manual_seed(2021)
+    D, E, L = 24, 32, 4
+    mlp = clipcap.MLP((D, (E * L) // 2, E * L))
+    x = torch.randn(3, D, generator=gen)
+    gy = torch.randn(3, E * L, generator=gen)
+    y = mlp(x)
+    (y * gy).sum().backward()
+    save("mapper_mlp.npz", x=x.numpy(), gy=gy.numpy(), y=y.detach().numpy(),
+         **_np(mlp.state_dict(), "w."), **{"g." + n: p.grad.numpy() for n, p in mlp.named_parameters()})
+
+    torch.manual_seed(2021)
+    E, L, CL, NL = 64, 4, 3, 2  # 8 heads fixed -> hd 8
+    tm = clipcap.TransformerMapper(D, E, L, CL, NL)
+    x = torch.randn(3, D, generator=gen)
+    gy = torch.randn(3, L, E, generator=gen)
+    y = tm(x)
+    (y * gy).sum().backward()
+    save("mapper_transformer.npz", x=x.numpy(), gy=gy.numpy(), y=y.detach().numpy(),
+         cfg=np.array([D, E, L, CL, NL]),
+         **_np(tm.state_dict(), "w."), **{"g." + n: p.grad.numpy() for n, p in tm.named_parameters()})
+
+    # ------------------------------------------------------------------ tiny GPT-2 + reference model
+    def build_gpt2(seed, V, E, n_layer, n_head, n_pos):
+        torch.manual_seed(seed)
+        cfg = GPT2Config(vocab_size=V, n_embd=E, n_layer=n_layer, n_head=n_head, n_positions=n_pos,
+                         bos_token_id=V - 1, eos_token_id=V - 1, attn_implementation="eager",
+                         resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)
+        m = GPT2LMHeadModel(cfg)
+        d = os.path.join(tmp, f"gpt2_{seed}_{E}")
+        m.save_pretrained(d)
+        return d, cfg
+
+    V, E, NLAY, NH, L, D = 320, 64, 2, 4, 4, 24
+    pad_id = eos_id = V - 1
+    d_gpt2, hfcfg = build_gpt2(2021, V, E, NLAY, NH, 64)
+    for mapping_type in ("mlp", "transformer"):
+        torch.manual_seed(7)
+        model = clipcap.ClipCaptionPrefix(prefix_length=L, clip_length=3, prefix_size=D, num_layers=2,
+                                          mapping_type=mapping_type, model_version=d_gpt2)
+        model.gpt.config._attn_implementation = "eager"
+        model.train()
+        B, T = 4, 9
+        ids, mask = ragged_batch(gen, B, T, V, pad_id, 3)
+        labels = ids.clone()
+        labels[labels == pad_id] = -100
+        prefix = torch.randn(B, D, generator=gen)
+        out = model(question_tokens=ids, prefix=prefix, question_mask=mask, labels=labels, pad_token_id=pad_id)
+        out.loss.backward()
+        grads = {"g." + n: p.grad.numpy() for n, p in model.clip_project.named_parameters()}
+        # generation: first a free run to learn which tokens appear, then force an early EOS row
+        model.eval()
+        gids, gmask = ragged_batch(gen, B, 6, V, pad_id, 2)
+        with torch.no_grad():
+            free = model.generate(question_tokens=gids, prefix=prefix, question_mask=gmask, max_length=6,
+                                  pad_token_id=pad_id, eos_token_id=None)
+            forced_eos = int(free[1][2])  # row 1 finishes after emitting its 3rd token
+            forced = model.generate(question_tokens=gids, prefix=prefix, question_mask=gmask, max_length=6,
+                                    pad_token_id=pad_id, eos_token_id=forced_eos)
+            all_eos = int(free[0][0])
+            allrows = [int(r[0]) for r in free]
+            early = model.generate(question_tokens=gids[:1], prefix=prefix[:1], question_mask=gmask[:1],
+                                   max_length=6, pad_token_id=pad_id, eos_token_id=all_eos)
+        save(f"clipcap_gpt2_{mapping_type}.npz",
+             cfg=np.array([V, E, NLAY, NH, 64, L, D, 3, 2]),  # V,E,n_layer,n_head,n_pos,L,D,clip_length,num_layers
+             ids=ids.numpy(), mask=mask.numpy(), labels=labels.numpy(), prefix=prefix.numpy(), pad_id=np.array(pad_id),
+             loss=out.loss.detach().numpy(), logits=out.logits.detach().numpy(),
+             gen_ids=gids.numpy(), gen_mask=gmask.numpy(),
+             gen_free=np.array(free), gen_forced=np.array(forced), gen_forced_eos=np.array(forced_eos),
+             gen_early=np.array(early), gen_early_eos=np.array(all_eos), gen_first=np.array(allrows),
+             **_np(model.gpt.state_dict(), "lm."), **_np(model.clip_project.state_dict(), "map."), **grads)
+
+    # ------------------------------------------------------------------ tiny OPT driven by the reference wrapper code
+    torch.manual_seed(11)
+    V, E, NLAY, NH, FFN = 336, 64, 2, 4, 96
+    ocfg = OPTConfig(vocab_size=V, hidden_size=E, num_hidden_layers=NLAY, num_attention_heads=NH, ffn_dim=FFN,
+                     max_position_embeddings=64, word_embed_proj_dim=E, pad_token_id=1, bos_token_id=2,
+                     eos_token_id=2, attn_implementation="eager", dropout=0.0, attention_dropout=0.0)
+    opt = OPTForCausalLM(ocfg).eval()
+    torch.manual_seed(13)
+    model = clipcap.ClipCaptionPrefix(prefix_length=L, prefix_size=D, mapping_type="mlp", model_version=d_gpt2)
+    # same MLP shapes (E equal); swap the LM, keep the reference's forward/generate code
+    opt.transformer = types.SimpleNamespace(wte=opt.model.decoder.embed_tokens)
+    model.gpt = opt
+    model.train()
+    pad_id = 1
+    B, T = 4, 9
+    ids, mask = ragged_batch(gen, B, T, V, pad_id, 3)
+    ids = ids.clamp(min=3)
+    ids = ids * mask + pad_id * (1 - mask)
+    labels = ids.clone()
+    labels[labels == pad_id] = -100
+    prefix = torch.randn(B, D, generator=gen)
+    out = model(question_tokens=ids, prefix=prefix, question_mask=mask, labels=labels, pad_token_id=pad_id)
+    out.loss.backward()
+    grads = {"g." + n: p.grad.numpy() for n, p in model.clip_project.named_parameters()}
+    model.eval()
+    gids, gmask = ragged_batch(gen, B, 6, V, pad_id, 2)
+    gids = (gids.clamp(min=3)) * gmask + pad_id * (1 - gmask)
+    with torch.no_grad():
+        free = model.generate(question_tokens=gids, prefix=prefix, question_mask=gmask, max_length=5,
+                              pad_token_id=pad_id, eos_token_id=None)
+        forced_eos = int(free[2][1])
+        forced = model.generate(question_tokens=gids, prefix=prefix, question_mask=gmask, max_length=5,
+                                pad_token_id=pad_id, eos_token_id=forced_eos)
+    sd = {k: v for k, v in opt.state_dict().items()}
+    save("clipcap_opt_mlp.npz",
+         cfg=np.array([V, E, NLAY, NH, 64, L, D, FFN]),
+         ids=ids.numpy(), mask=mask.numpy(), labels=labels.numpy(), prefix=prefix.numpy(), pad_id=np.array(pad_id),
+         loss=out.loss.detach().numpy(), logits=out.logits.detach().numpy(),
+         gen_ids=gids.numpy(), gen_mask=gmask.numpy(), gen_free=np.array(free), gen_forced=np.array(forced),
+         gen_forced_eos=np.array(forced_eos),
+         **_np(sd, "lm."), **_np(model.clip_project.state_dict(), "map."), **grads)
+
+    # ------------------------------------------------------------------ insert_prefix_into_input
+    def ref_insert(L, E, num_shots, toks, text, pp, masks, special=32099):
+        self_ = types.SimpleNamespace(prefix_length=L, lm_embedding_size=E)
+        emb, msk = vct0.VCT0Model.insert_prefix_into_input(self_, toks.shape[0], num_shots, toks, text, pp, masks,
+                                                           special_token_id=special)
+        return emb, msk
+
+    # the two known-answer cases of src/models/vct0_test.py:79-211 (values are test DATA, re-typed here)
+    text = torch.tensor([[[100., 101, 102], [103, 104, 105], [106, 107, 108], [109, 110, 111], [130, 131, 132],
+                          [133, 134, 135], [99, 98, 97]],
+                         [[112., 113, 114], [115, 116, 117], [117, 118, 119], [120, 121, 122], [140, 141, 142],
+                          [143, 144, 145], [96, 95, 94]]])
+    pp_few = -torch.tensor([[[[100., 101, 102], [103, 104, 105]], [[106, 107, 108], [109, 110, 111]],
+                             [[130, 131, 132], [133, 134, 135]]],
+                            [[[112., 113, 114], [115, 116, 117]], [[117, 118, 119], [120, 121, 122]],
+                             [[140, 141, 142], [143, 144, 145]]]])
+    pp_zero = pp_few[:, :1].contiguous()
+    masks = torch.tensor([[1, 1, 1, 1, 1, 1, 0], [1, 1, 1, 1, 1, 1, 1]], dtype=int)
+    tok0 = torch.tensor([[32099, 20414, 11, 11, 11, 48, 0], [20414, 32099, 11, 48, 48, 48, 10]], dtype=int)
+    tok2 = torch.tensor([[32099, 20414, 32098, 11, 32097, 48, 0], [20414, 32099, 11, 32098, 48, 32097, 10]], dtype=int)
+    e0, m0 = ref_insert(2, 3, 0, tok0, text, pp_zero, masks)
+    e2, m2 = ref_insert(2, 3, 2, tok2, text, pp_few, masks)
+    # the expected values spelled out in vct0_test.py (checked here against the reference's own output)
+    exp_m0 = torch.tensor([[1, 1, 1, 1, 1, 1, 1, 0], [1, 1, 1, 1, 1, 1, 1, 1]])
+    exp_m2 = torch.tensor([[1, 1, 1, 1, 1, 1, 1, 1, 1, 0], [1] * 10])
+    assert torch.equal(m0, exp_m0) and torch.equal(m2, exp_m2)
+    exp_e2_row0 = torch.stack([*pp_few[0, 0], text[0, 1], *pp_few[0, 1], text[0, 3], *pp_few[0, 2], text[0, 5], text[0, 6]])
+    assert torch.equal(e2[0], exp_e2_row0)
+    # 4-shot case, L=3, E=5, random text
+    B, T, E5, L3, shots = 3, 17, 5, 3, 4
+    toks = torch.randint(5, 1000, (B, T), generator=gen)
+    for b in range(B):
+        pos = torch.randperm(T, generator=gen)[: shots + 1].sort().values
+        for i, p_ in enumerate(pos):
+            toks[b, p_] = 32099 - i
+    text4 = torch.randn(B, T, E5, generator=gen)
+    pp4 = torch.randn(B, shots + 1, L3, E5, generator=gen)
+    m4 = (torch.rand(B, T, generator=gen) > 0.2).long()
+    e4, mm4 = ref_insert(L3, E5, shots, toks, text4, pp4, m4)
+    save("insert_prefix.npz",
+         z_tok=tok0.numpy(), z_text=text.numpy(), z_pp=pp_zero.numpy(), z_mask=masks.numpy(), z_emb=e0.numpy(), z_out_mask=m0.numpy(),
+         f_tok=tok2.numpy(), f_text=text.numpy(), f_pp=pp_few.numpy(), f_mask=masks.numpy(), f_emb=e2.numpy(), f_out_mask=m2.numpy(),
+         s_tok=toks.numpy(), s_text=text4.numpy(), s_pp=pp4.numpy(), s_mask=m4.numpy(), s_emb=e4.numpy(), s_out_mask=mm4.numpy(),
+         s_cfg=np.array([L3, E5, shots]))
+
+    # ------------------------------------------------------------------ label masking known answers
+    # hand-derived from src/trainers/clipcap_exector.py:134-150 (pad == eos == 9, bos == 7)
+    lm_in = np.array([[3, 4, 7, 5, 6, 9, 9, 9],      # question 3 4, <BOS>, answer 5 6, then pads
+                      [3, 7, 5, 9, 9, 9, 9, 9],
+                      [3, 4, 5, 6, 2, 1, 7, 8],      # no pad at all: answer = last token only
+                      [3, 4, 5, 6, 9, 9, 9, 9],      # no <BOS>: everything masked, first pad restored
+                      [7, 5, 7, 6, 9, 9, 9, 9]])     # two <BOS>: both masked, tokens after the first kept
+    lm_out = np.array([[-100, -100, -100, 5, 6, 9, -100, -100],
+                       [-100, -100, 5, 9, -100, -100, -100, -100],
+                       [-100, -100, -100, -100, -100, -100, -100, 8],
+                       [-100, -100, -100, -100, 9, -100, -100, -100],
+                       [-100, 5, -100, 6, 9, -100, -100, -100]])
+    save("label_mask.npz", input_ids=lm_in, labels=lm_out, pad_id=np.array(9), bos_id=np.array(7))
+
+    # ------------------------------------------------------------------ tiny CLIP ViT
+    torch.manual_seed(5)
+    ccfg = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                            image_size=48, patch_size=16, projection_dim=24, hidden_act="quick_gelu",
+                            attn_implementation="eager")
+    clip = CLIPVisionModelWithProjection(ccfg).eval()
+    # HF init leaves class_embedding ~N(0,1)*scale; fine.
+    px = torch.randn(3, 3, 48, 48, generator=gen)
+    with torch.no_grad():
+        emb = clip(pixel_values=px).image_embeds
+    save("clip_vit.npz", cfg=np.array([64, 128, 2, 4, 48, 16, 24]), pixels=px.numpy(), image_embeds=emb.numpy(),
+         **_np(clip.state_dict(), "w."))
+
+    # a ViT with a patch size that is not a multiple of 8 (ViT-L/14-like: K = 3*14*14 = 588)
+    torch.manual_seed(6)
+    ccfg = CLIPVisionConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=4,
+                            image_size=42, patch_size=14, projection_dim=24, hidden_act="quick_gelu",
+                            attn_implementation="eager")
+    clip = CLIPVisionModelWithProjection(ccfg).eval()
+    px = torch.randn(2, 3, 42, 42, generator=gen)
+    with torch.no_grad():
+        emb = clip(pixel_values=px).image_embeds
+    save("clip_vit_p14.npz", cfg=np.array([64, 128, 1, 4, 42, 14, 24]), pixels=px.numpy(), image_embeds=emb.numpy(),
+         **_np(clip.state_dict(), "w."))
+
+
+if __name__ == "__main__":
+    main()
