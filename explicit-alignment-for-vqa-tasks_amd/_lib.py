@@ -1,0 +1,81 @@
+"""ctypes binding of libeavqa_hip.so (the C ABI declared in include/eavqa.h).
+
+The product path has NO fallback: if the shared library is missing or a call returns an error
+code, an exception is raised.  The signature table below mirrors include/eavqa.h one-for-one;
+``tests/test_abi.py`` checks that every ``eavqa_*`` function declared in the header is exported
+by the library and listed here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libeavqa_hip.so")
+
+F32, BF16 = 0, 1
+ACT = {"none": 0, "tanh": 1, "relu": 2, "gelu_new": 3, "quick_gelu": 4}
+
+i32, i64, f32, ptr = C.c_int, C.c_int64, C.c_float, C.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "eavqa_abi_version": [],
+    "eavqa_strerror": [i32],
+    "eavqa_check_device": [],
+    "eavqa_gemm": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i32, f32, ptr, i32, ptr, ptr, i64, ptr, i64, ptr],
+    "eavqa_layernorm_fwd": [i32, i32, i32, i32, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, ptr, ptr],
+    "eavqa_layernorm_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr],
+    "eavqa_attention_fwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i32, f32, ptr, ptr],
+    "eavqa_attention_bwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64,
+                            ptr, i64, ptr, i64, ptr, i64, ptr, i32, f32, ptr, ptr, ptr],
+    "eavqa_build_prefix_rows": [i32, i32, i32, ptr, ptr, i32, ptr, ptr, ptr, ptr],
+    "eavqa_build_fewshot_rows": [i32, i32, i32, i32, i64, ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr],
+    "eavqa_embed_assemble": [i32, i32, i32, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr],
+    "eavqa_embed_assemble_bwd": [i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr],
+    "eavqa_build_labels": [i32, i32, i32, i32, ptr, i64, i64, ptr, ptr],
+    "eavqa_ce_fwd": [i32, i32, i32, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr],
+    "eavqa_ce_bwd": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr],
+    "eavqa_greedy_pick": [i32, i32, ptr, i64, i64, i64, ptr, ptr, i64, ptr, ptr],
+    "eavqa_adamw": [i64, ptr, ptr, ptr, ptr, i32, f32, f32, f32, f32, f32, f32, i32, ptr, ptr],
+    "eavqa_patchify": [i32, i32, i32, i32, ptr, ptr, i64, ptr],
+    "eavqa_vit_assemble": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, i64, ptr],
+    "eavqa_cast_rows": [i32, i32, i32, ptr, i64, ptr, i64, ptr],
+}
+_RESTYPES = {"eavqa_strerror": C.c_char_p}
+
+_lib = None
+
+
+class EavqaError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise (never fall back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EavqaError(
+            f"{LIB_PATH} is missing: the HIP extension is the only compute path. "
+            "Build it with `python -m eavqa_amd.build` (needs hipcc, no GPU required to compile)."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    got = lib.eavqa_abi_version()
+    if got != 1:
+        raise EavqaError(f"libeavqa_hip.so ABI version {got}, host code expects 1")
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> None:
+    """Invoke an int-returning entry point and raise on a non-zero code."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise EavqaError(f"{name} failed: {lib.eavqa_strerror(rc).decode()} (code {rc})")

@@ -1,0 +1,418 @@
+// Attention forward / backward, fp32 arithmetic on the vector ALU, generic over the storage
+// type (eavqa_attention_fwd / _bwd in include/eavqa.h).
+//
+// This is the exact-arithmetic path used for parity in both dtypes; the sequences on this hot
+// path are short (LM: S = 42..200, ViT: N = 50..577, mapper: 20), so each workgroup streams
+// 64-key (or 64-query) tiles of one (batch, head) through LDS as fp32 and every query row
+// (key row in the dK/dV pass) is owned by LPR adjacent lanes that each hold hd/LPR dims in
+// registers.  Softmax is online (running max / sum per row), scores are processed in chunks of
+// 8 keys so that the accumulator rescale is paid once per chunk.
+//
+// Masking: a masked score is REPLACED by -FLT_MAX (HF adds finfo.min to a score that is
+// negligible against it), so a fully masked row degrades to the uniform average, never NaN.
+#include "common.h"
+
+namespace {
+
+constexpr int CK = 8;  // keys per softmax chunk
+
+struct AttnParams {
+    const void* q; const void* k; const void* v; const void* o; const void* d_o;
+    void* out;   // fwd: o
+    void* dq; void* dk; void* dv;
+    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    const int32_t* key_mask;
+    float* lse; float* delta;
+    int B, H, Sq, Sk, hd, causal, tile;
+    int64_t bsq, bsk;   // rows between consecutive batches of q/o/do/dq and of k/v/dk/dv
+    float scale;
+};
+
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// cooperative load of `nrows` rows (row index r0.., bound rmax) of one head into LDS as fp32 [tile][hd]
+template <typename T>
+__device__ __forceinline__ void stage_rows(float* dst, const T* src, int64_t ld, int64_t base_row, int r0, int rmax,
+                                           int tile, int hd, int head_off) {
+    const int per_row = hd >> 2;
+    const int total = tile * per_row;
+    for (int c = threadIdx.x; c < total; c += blockDim.x) {
+        const int r = c / per_row, d4 = c - r * per_row;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r0 + r < rmax) val = elem<T>::ld4(src + (base_row + r0 + r) * ld + head_off + 4 * d4);
+        *reinterpret_cast<float4*>(dst + r * hd + 4 * d4) = val;
+    }
+}
+
+// ------------------------------------------------------------------ forward
+template <typename T, int LPR, int DP4>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Ks = reinterpret_cast<float*>(smem_raw);
+    float* Vs = Ks + p.tile * p.hd;
+    int* valid = reinterpret_cast<int*>(Vs + p.tile * p.hd);
+
+    constexpr int ROWS = 256 / LPR;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int r_local = threadIdx.x / LPR, part = threadIdx.x % LPR;
+    const int r0 = blockIdx.x * ROWS;
+    const int i = r0 + r_local;                 // query row
+    const bool active = i < p.Sq;
+    const int off = p.Sk - p.Sq;                // causal: key j visible iff j <= i + off
+    const int head_off = h * p.hd;
+    const int dbase = part * (DP4 * 4);
+    const T* Q = reinterpret_cast<const T*>(p.q);
+    const T* K = reinterpret_cast<const T*>(p.k);
+    const T* V = reinterpret_cast<const T*>(p.v);
+
+    float4 qv[DP4], acc[DP4];
+#pragma unroll
+    for (int d = 0; d < DP4; ++d) {
+        qv[d] = active ? elem<T>::ld4(Q + ((int64_t)b * p.bsq + i) * p.ldq + head_off + dbase + 4 * d)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float m = -FLT_MAX, l = 0.f;
+
+    // last key any row of this block may see
+    int k_end = p.Sk;
+    if (p.causal) { const int last = min(p.Sq, r0 + ROWS) - 1 + off; k_end = min(p.Sk, last + 1); }
+    if (k_end < 1) k_end = min(p.Sk, 1);
+
+    for (int k0 = 0; k0 < k_end; k0 += p.tile) {
+        __syncthreads();
+        stage_rows<T>(Ks, K, p.ldk, (int64_t)b * p.bsk, k0, p.Sk, p.tile, p.hd, head_off);
+        stage_rows<T>(Vs, V, p.ldv, (int64_t)b * p.bsk, k0, p.Sk, p.tile, p.hd, head_off);
+        for (int c = threadIdx.x; c < p.tile; c += blockDim.x)
+            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.Sk + k0 + c] != 0);
+        __syncthreads();
+        const int nkeys = min(p.tile, p.Sk - k0);
+        for (int c0 = 0; c0 < nkeys; c0 += CK) {
+            float sc[CK];
+            float cmax = -FLT_MAX;
+#pragma unroll
+            for (int c = 0; c < CK; ++c) {
+                const int j = c0 + c;
+                float s = 0.f;
+                if (j < nkeys) {
+                    const float* kr = Ks + j * p.hd + dbase;
+#pragma unroll
+                    for (int d = 0; d < DP4; ++d) {
+                        const float4 kv = *reinterpret_cast<const float4*>(kr + 4 * d);
+                        s += qv[d].x * kv.x + qv[d].y * kv.y + qv[d].z * kv.z + qv[d].w * kv.w;
+                    }
+                }
+                s = group_sum<LPR>(s) * p.scale;
+                const bool vis = (j < nkeys) && valid[j] && (!p.causal || (k0 + j) <= i + off);
+                sc[c] = (j < nkeys) ? (vis ? s : -FLT_MAX) : -INFINITY;   // -inf: key does not exist
+                cmax = fmaxf(cmax, sc[c]);
+            }
+            const float m_new = fmaxf(m, cmax);
+            const float corr = expf(m - m_new);
+            l *= corr;
+#pragma unroll
+            for (int d = 0; d < DP4; ++d) { acc[d].x *= corr; acc[d].y *= corr; acc[d].z *= corr; acc[d].w *= corr; }
+#pragma unroll
+            for (int c = 0; c < CK; ++c) {
+                const int j = c0 + c;
+                if (j < nkeys) {
+                    const float pj = expf(sc[c] - m_new);
+                    l += pj;
+                    const float* vr = Vs + j * p.hd + dbase;
+#pragma unroll
+                    for (int d = 0; d < DP4; ++d) {
+                        const float4 vv = *reinterpret_cast<const float4*>(vr + 4 * d);
+                        acc[d].x += pj * vv.x; acc[d].y += pj * vv.y; acc[d].z += pj * vv.z; acc[d].w += pj * vv.w;
+                    }
+                }
+            }
+            m = m_new;
+        }
+    }
+    if (active) {
+        const float inv = 1.f / l;
+        T* O = reinterpret_cast<T*>(p.out);
+#pragma unroll
+        for (int d = 0; d < DP4; ++d)
+            elem<T>::st4(O + ((int64_t)b * p.bsq + i) * p.ldo + head_off + dbase + 4 * d,
+                         make_float4(acc[d].x * inv, acc[d].y * inv, acc[d].z * inv, acc[d].w * inv));
+        if (p.lse && part == 0) p.lse[((int64_t)b * p.H + h) * p.Sq + i] = m + logf(l);
+    }
+}
+
+// ------------------------------------------------------------------ backward, dQ (+ delta)
+template <typename T, int LPR, int DP4>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Ks = reinterpret_cast<float*>(smem_raw);
+    float* Vs = Ks + p.tile * p.hd;
+    int* valid = reinterpret_cast<int*>(Vs + p.tile * p.hd);
+
+    constexpr int ROWS = 256 / LPR;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int r_local = threadIdx.x / LPR, part = threadIdx.x % LPR;
+    const int r0 = blockIdx.x * ROWS;
+    const int i = r0 + r_local;
+    const bool active = i < p.Sq;
+    const int off = p.Sk - p.Sq;
+    const int head_off = h * p.hd;
+    const int dbase = part * (DP4 * 4);
+    const T* Q = reinterpret_cast<const T*>(p.q);
+    const T* K = reinterpret_cast<const T*>(p.k);
+    const T* V = reinterpret_cast<const T*>(p.v);
+    const T* O = reinterpret_cast<const T*>(p.o);
+    const T* DO = reinterpret_cast<const T*>(p.d_o);
+
+    float4 qv[DP4], dov[DP4], dq[DP4];
+    float dsum = 0.f;
+#pragma unroll
+    for (int d = 0; d < DP4; ++d) {
+        const int64_t row = (int64_t)b * p.bsq + i;
+        const int col = head_off + dbase + 4 * d;
+        qv[d] = active ? elem<T>::ld4(Q + row * p.ldq + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dov[d] = active ? elem<T>::ld4(DO + row * p.lddo + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 ov = active ? elem<T>::ld4(O + row * p.ldo + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dsum += dov[d].x * ov.x + dov[d].y * ov.y + dov[d].z * ov.z + dov[d].w * ov.w;
+        dq[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float delta = group_sum<LPR>(dsum);
+    const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + i;
+    const float lse = active ? p.lse[stat] : 0.f;
+    if (active && part == 0) p.delta[stat] = delta;
+
+    int k_end = p.Sk;
+    if (p.causal) { const int last = min(p.Sq, r0 + ROWS) - 1 + off; k_end = min(p.Sk, last + 1); }
+    if (k_end < 1) k_end = min(p.Sk, 1);
+
+    for (int k0 = 0; k0 < k_end; k0 += p.tile) {
+        __syncthreads();
+        stage_rows<T>(Ks, K, p.ldk, (int64_t)b * p.bsk, k0, p.Sk, p.tile, p.hd, head_off);
+        stage_rows<T>(Vs, V, p.ldv, (int64_t)b * p.bsk, k0, p.Sk, p.tile, p.hd, head_off);
+        for (int c = threadIdx.x; c < p.tile; c += blockDim.x)
+            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.Sk + k0 + c] != 0);
+        __syncthreads();
+        const int nkeys = min(p.tile, p.Sk - k0);
+        for (int j = 0; j < nkeys; ++j) {
+            const float* kr = Ks + j * p.hd + dbase;
+            const float* vr = Vs + j * p.hd + dbase;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP4; ++d) {
+                const float4 kv = *reinterpret_cast<const float4*>(kr + 4 * d);
+                const float4 vv = *reinterpret_cast<const float4*>(vr + 4 * d);
+                s += qv[d].x * kv.x + qv[d].y * kv.y + qv[d].z * kv.z + qv[d].w * kv.w;
+                dp += dov[d].x * vv.x + dov[d].y * vv.y + dov[d].z * vv.z + dov[d].w * vv.w;
+            }
+            s = group_sum<LPR>(s) * p.scale;
+            dp = group_sum<LPR>(dp);
+            const bool vis = valid[j] && (!p.causal || (k0 + j) <= i + off);
+            const float pj = expf((vis ? s : -FLT_MAX) - lse);
+            const float ds = pj * (dp - delta) * p.scale;
+#pragma unroll
+            for (int d = 0; d < DP4; ++d) {
+                const float4 kv = *reinterpret_cast<const float4*>(kr + 4 * d);
+                dq[d].x += ds * kv.x; dq[d].y += ds * kv.y; dq[d].z += ds * kv.z; dq[d].w += ds * kv.w;
+            }
+        }
+    }
+    if (active) {
+        T* DQ = reinterpret_cast<T*>(p.dq);
+#pragma unroll
+        for (int d = 0; d < DP4; ++d)
+            elem<T>::st4(DQ + ((int64_t)b * p.bsq + i) * p.lddq + head_off + dbase + 4 * d, dq[d]);
+    }
+}
+
+// ------------------------------------------------------------------ backward, dK and dV
+template <typename T, int LPR, int DP4>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Qs = reinterpret_cast<float*>(smem_raw);
+    float* DOs = Qs + p.tile * p.hd;
+    float* stats = DOs + p.tile * p.hd;  // [tile] lse then [tile] delta
+
+    constexpr int ROWS = 256 / LPR;
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int r_local = threadIdx.x / LPR, part = threadIdx.x % LPR;
+    const int j0 = blockIdx.x * ROWS;
+    const int j = j0 + r_local;                 // key row
+    const bool active = j < p.Sk;
+    const int off = p.Sk - p.Sq;
+    const int head_off = h * p.hd;
+    const int dbase = part * (DP4 * 4);
+    const T* Q = reinterpret_cast<const T*>(p.q);
+    const T* K = reinterpret_cast<const T*>(p.k);
+    const T* V = reinterpret_cast<const T*>(p.v);
+    const T* DO = reinterpret_cast<const T*>(p.d_o);
+
+    float4 kv[DP4], vv[DP4], dk[DP4], dv[DP4];
+#pragma unroll
+    for (int d = 0; d < DP4; ++d) {
+        const int64_t row = (int64_t)b * p.bsk + j;
+        const int col = head_off + dbase + 4 * d;
+        kv[d] = active ? elem<T>::ld4(K + row * p.ldk + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        vv[d] = active ? elem<T>::ld4(V + row * p.ldv + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dk[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dv[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool kvalid = active && (!p.key_mask || p.key_mask[(int64_t)b * p.Sk + j] != 0);
+
+    // first query any key of this block is visible to: i >= j - off
+    int q_begin = 0;
+    if (p.causal) q_begin = max(0, j0 - off);
+    q_begin = (q_begin / p.tile) * p.tile;
+
+    for (int q0 = q_begin; q0 < p.Sq; q0 += p.tile) {
+        __syncthreads();
+        stage_rows<T>(Qs, Q, p.ldq, (int64_t)b * p.bsq, q0, p.Sq, p.tile, p.hd, head_off);
+        stage_rows<T>(DOs, DO, p.lddo, (int64_t)b * p.bsq, q0, p.Sq, p.tile, p.hd, head_off);
+        for (int c = threadIdx.x; c < p.tile; c += blockDim.x) {
+            const bool in = q0 + c < p.Sq;
+            const int64_t st = ((int64_t)b * p.H + h) * p.Sq + q0 + c;
+            stats[c] = in ? p.lse[st] : 0.f;
+            stats[p.tile + c] = in ? p.delta[st] : 0.f;
+        }
+        __syncthreads();
+        const int nq = min(p.tile, p.Sq - q0);
+        for (int c = 0; c < nq; ++c) {
+            const int i = q0 + c;
+            const float* qr = Qs + c * p.hd + dbase;
+            const float* dor = DOs + c * p.hd + dbase;
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP4; ++d) {
+                const float4 qq = *reinterpret_cast<const float4*>(qr + 4 * d);
+                const float4 dd = *reinterpret_cast<const float4*>(dor + 4 * d);
+                s += qq.x * kv[d].x + qq.y * kv[d].y + qq.z * kv[d].z + qq.w * kv[d].w;
+                dp += dd.x * vv[d].x + dd.y * vv[d].y + dd.z * vv[d].z + dd.w * vv[d].w;
+            }
+            s = group_sum<LPR>(s) * p.scale;
+            dp = group_sum<LPR>(dp);
+            const bool vis = kvalid && (!p.causal || j <= i + off);
+            const float pj = expf((vis ? s : -FLT_MAX) - stats[c]);
+            const float ds = pj * (dp - stats[p.tile + c]) * p.scale;
+#pragma unroll
+            for (int d = 0; d < DP4; ++d) {
+                const float4 qq = *reinterpret_cast<const float4*>(qr + 4 * d);
+                const float4 dd = *reinterpret_cast<const float4*>(dor + 4 * d);
+                dv[d].x += pj * dd.x; dv[d].y += pj * dd.y; dv[d].z += pj * dd.z; dv[d].w += pj * dd.w;
+                dk[d].x += ds * qq.x; dk[d].y += ds * qq.y; dk[d].z += ds * qq.z; dk[d].w += ds * qq.w;
+            }
+        }
+    }
+    if (active) {
+        T* DK = reinterpret_cast<T*>(p.dk);
+        T* DV = reinterpret_cast<T*>(p.dv);
+#pragma unroll
+        for (int d = 0; d < DP4; ++d) {
+            const int64_t row = (int64_t)b * p.bsk + j;
+            const int col = head_off + dbase + 4 * d;
+            elem<T>::st4(DK + row * p.lddk + col, dk[d]);
+            elem<T>::st4(DV + row * p.lddv + col, dv[d]);
+        }
+    }
+}
+
+enum { K_FWD = 0, K_DQ = 1, K_DKV = 2 };
+
+template <typename T, int LPR, int DP4>
+int launch_cfg(int which, AttnParams& p, hipStream_t s) {
+    constexpr int ROWS = 256 / LPR;
+    // tile rows so that two fp32 [tile][hd] images fit in 64 KiB
+    int tile = 64;
+    while (tile > 8 && (size_t)tile * p.hd * 8 > 60 * 1024) tile >>= 1;
+    p.tile = tile;
+    const size_t lds = (size_t)tile * p.hd * 8 + (size_t)tile * 8;
+    if (which == K_FWD) {
+        dim3 grid((p.Sq + ROWS - 1) / ROWS, p.B * p.H);
+        hipLaunchKernelGGL((attn_fwd_kernel<T, LPR, DP4>), grid, dim3(256), lds, s, p);
+    } else if (which == K_DQ) {
+        dim3 grid((p.Sq + ROWS - 1) / ROWS, p.B * p.H);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<T, LPR, DP4>), grid, dim3(256), lds, s, p);
+    } else {
+        dim3 grid((p.Sk + ROWS - 1) / ROWS, p.B * p.H);
+        hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, LPR, DP4>), grid, dim3(256), lds, s, p);
+    }
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+// lanes per row / float4 per lane for a head dim (hd = LPR * DP4 * 4)
+template <typename T>
+int dispatch(int which, AttnParams& p, hipStream_t s) {
+    const int hd = p.hd;
+#define EAVQA_ATTN_CASE(L, D) if (hd == (L) * (D) * 4) return launch_cfg<T, L, D>(which, p, s)
+    EAVQA_ATTN_CASE(4, 4);   // 64
+    EAVQA_ATTN_CASE(4, 5);   // 80
+    EAVQA_ATTN_CASE(4, 6);   // 96
+    EAVQA_ATTN_CASE(4, 8);   // 128
+    EAVQA_ATTN_CASE(8, 5);   // 160
+    EAVQA_ATTN_CASE(8, 8);   // 256
+    EAVQA_ATTN_CASE(16, 5);  // 320
+    EAVQA_ATTN_CASE(16, 8);  // 512
+    EAVQA_ATTN_CASE(4, 1);   // 16
+    EAVQA_ATTN_CASE(4, 2);   // 32
+    EAVQA_ATTN_CASE(4, 3);   // 48
+    EAVQA_ATTN_CASE(2, 1);   // 8
+    EAVQA_ATTN_CASE(1, 1);   // 4
+#undef EAVQA_ATTN_CASE
+    return EAVQA_E_SHAPE;
+}
+
+int check_common(int dtype, int B, int H, int Sq, int Sk, int hd) {
+    if (B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || hd <= 0) return EAVQA_E_ARG;
+    if (dtype != EAVQA_F32 && dtype != EAVQA_BF16) return EAVQA_E_DTYPE;
+    if (hd % 4) return EAVQA_E_SHAPE;
+    if ((int64_t)B * H > 65535) return EAVQA_E_SHAPE;
+    return EAVQA_OK;
+}
+
+}  // namespace
+
+extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,
+                                   const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                   const void* v, int64_t ldv, void* o, int64_t ldo,
+                                   int64_t q_batch_rows, int64_t kv_batch_rows,
+                                   const int32_t* key_mask, int causal, float scale, float* lse, void* stream) {
+    if (!q || !k || !v || !o) return EAVQA_E_ARG;
+    int rc = check_common(dtype, B, H, Sq, Sk, hd);
+    if (rc) return rc;
+    if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return EAVQA_E_ALIGN;
+    AttnParams p = {};
+    p.q = q; p.k = k; p.v = v; p.out = o; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.key_mask = key_mask; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.hd = hd;
+    p.causal = causal; p.scale = scale;
+    p.bsq = q_batch_rows > 0 ? q_batch_rows : Sq;
+    p.bsk = kv_batch_rows > 0 ? kv_batch_rows : Sk;
+    if (p.bsq < Sq || p.bsk < Sk) return EAVQA_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == EAVQA_F32 ? dispatch<float>(K_FWD, p, s) : dispatch<bf16_t>(K_FWD, p, s);
+}
+
+extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int hd,
+                                   const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                   const void* v, int64_t ldv, const void* o, int64_t ldo,
+                                   const void* d_o, int64_t lddo,
+                                   void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                                   const int32_t* key_mask, int causal, float scale,
+                                   const float* lse, float* delta, void* stream) {
+    if (!q || !k || !v || !o || !d_o || !dq || !dk || !dv || !lse || !delta) return EAVQA_E_ARG;
+    int rc = check_common(dtype, B, H, Sq, Sk, hd);
+    if (rc) return rc;
+    if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || lddo % 4 || lddq % 4 || lddk % 4 || lddv % 4) return EAVQA_E_ALIGN;
+    AttnParams p = {};
+    p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    p.key_mask = key_mask; p.lse = const_cast<float*>(lse); p.delta = delta;
+    p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.hd = hd; p.causal = causal; p.scale = scale;
+    p.bsq = Sq; p.bsk = Sk;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rc = dtype == EAVQA_F32 ? dispatch<float>(K_DQ, p, s) : dispatch<bf16_t>(K_DQ, p, s);
+    if (rc) return rc;
+    return dtype == EAVQA_F32 ? dispatch<float>(K_DKV, p, s) : dispatch<bf16_t>(K_DKV, p, s);
+}

@@ -1,0 +1,192 @@
+// LayerNorm forward / backward (eavqa_layernorm_fwd / _bwd in include/eavqa.h).
+// HBM-bound: one wavefront (64 lanes) owns one row, the row lives in registers between the
+// statistics passes, every global access is a 16-byte (fp32) or 8-byte (bf16) vector.
+// Algorithmic bytes per row: fwd = cols*(sizeof x + sizeof y); bwd = cols*(x + dy + dres + dx).
+#include "common.h"
+
+namespace {
+
+constexpr int LN_MAX_V4 = 32;  // float4 per lane: cols <= 64 * 4 * 32 = 8192
+constexpr int LN_WAVES = 4;    // rows per 256-thread block
+
+template <typename T>
+__device__ __forceinline__ float4 ldrow4(const void* base, int64_t off, bool f32) {
+    if (f32) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+    return elem<T>::ld4(reinterpret_cast<const T*>(base) + off);
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(int x_f32, int rows, int cols, const void* x, int64_t ldx,
+                                                     const float* gamma, const float* beta, float eps,
+                                                     T* y, int64_t ldy, float* mean, float* rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = cols >> 2;
+    float4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = ldrow4<T>(x, (int64_t)row * ldx + 4 * c, x_f32);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) {
+        if (mean) mean[row] = mu;
+        if (rstd) rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            float4 b = beta ? *reinterpret_cast<const float4*>(beta + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o;
+            o.x = (v[i].x - mu) * rs * g.x + b.x;
+            o.y = (v[i].y - mu) * rs * g.y + b.y;
+            o.z = (v[i].z - mu) * rs * g.z + b.z;
+            o.w = (v[i].w - mu) * rs * g.w + b.w;
+            elem<T>::st4(y + (int64_t)row * ldy + 4 * c, o);
+        }
+    }
+}
+
+// dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(int x_f32, int rows, int cols, const void* x, int64_t ldx,
+                                                     const T* dy, int64_t lddy, const float* gamma,
+                                                     const float* mean, const float* rstd, const float* dres,
+                                                     float* dx, int64_t lddx, float* dgamma, float* dbeta) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = cols >> 2;
+    const float mu = mean[row], rs = rstd[row];
+    float4 xh[NV], gd[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float4 xv = ldrow4<T>(x, (int64_t)row * ldx + 4 * c, x_f32);
+            float4 d = elem<T>::ld4(dy + (int64_t)row * lddy + 4 * c);
+            float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+            if (dgamma) {
+                atomicAdd(dgamma + 4 * c + 0, d.x * xh[i].x);
+                atomicAdd(dgamma + 4 * c + 1, d.y * xh[i].y);
+                atomicAdd(dgamma + 4 * c + 2, d.z * xh[i].z);
+                atomicAdd(dgamma + 4 * c + 3, d.w * xh[i].w);
+            }
+            if (dbeta) {
+                atomicAdd(dbeta + 4 * c + 0, d.x);
+                atomicAdd(dbeta + 4 * c + 1, d.y);
+                atomicAdd(dbeta + 4 * c + 2, d.z);
+                atomicAdd(dbeta + 4 * c + 3, d.w);
+            }
+            gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+            s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
+            s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+        } else {
+            xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gd[i] = xh[i];
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)cols;
+    const float m2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            float4 r = dres ? *reinterpret_cast<const float4*>(dres + (int64_t)row * lddx + 4 * c)
+                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o;
+            o.x = r.x + rs * (gd[i].x - m1 - xh[i].x * m2);
+            o.y = r.y + rs * (gd[i].y - m1 - xh[i].y * m2);
+            o.z = r.z + rs * (gd[i].z - m1 - xh[i].z * m2);
+            o.w = r.w + rs * (gd[i].w - m1 - xh[i].w * m2);
+            *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + 4 * c) = o;
+        }
+    }
+}
+
+template <typename T>
+int ln_fwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                    float eps, void* y, int64_t ldy, float* mean, float* rstd, hipStream_t s) {
+    const int nv = (cols / 4 + 63) / 64;
+    dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(256);
+#define EAVQA_LN_FWD(NV)                                                                                         \
+    hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, block, 0, s, x_f32, rows, cols, x, ldx, gamma, beta, eps, \
+                       reinterpret_cast<T*>(y), ldy, mean, rstd)
+    if (nv <= 2) EAVQA_LN_FWD(2);
+    else if (nv <= 4) EAVQA_LN_FWD(4);
+    else if (nv <= 8) EAVQA_LN_FWD(8);
+    else if (nv <= 16) EAVQA_LN_FWD(16);
+    else EAVQA_LN_FWD(32);
+#undef EAVQA_LN_FWD
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+template <typename T>
+int ln_bwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, const void* dy, int64_t lddy,
+                    const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
+                    int64_t lddx, float* dgamma, float* dbeta, hipStream_t s) {
+    const int nv = (cols / 4 + 63) / 64;
+    dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(256);
+#define EAVQA_LN_BWD(NV)                                                                                   \
+    hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, 0, s, x_f32, rows, cols, x, ldx,               \
+                       reinterpret_cast<const T*>(dy), lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta)
+    if (nv <= 2) EAVQA_LN_BWD(2);
+    else if (nv <= 4) EAVQA_LN_BWD(4);
+    else if (nv <= 8) EAVQA_LN_BWD(8);
+    else if (nv <= 16) EAVQA_LN_BWD(16);
+    else return EAVQA_E_SHAPE;  // 2 x 32 float4 per lane would spill; cols <= 4096 in backward
+#undef EAVQA_LN_BWD
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+}  // namespace
+
+extern "C" int eavqa_layernorm_fwd(int dtype, int x_f32, int rows, int cols, const void* x, int64_t ldx,
+                                   const float* gamma, const float* beta, float eps, void* y, int64_t ldy,
+                                   float* mean, float* rstd, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0) return EAVQA_E_ARG;
+    if (cols % 4 || cols > 64 * 4 * LN_MAX_V4) return EAVQA_E_SHAPE;
+    if (ldx % 4 || ldy % 4) return EAVQA_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32) return ln_fwd_dispatch<float>(1, rows, cols, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, s);
+    if (dtype == EAVQA_BF16) return ln_fwd_dispatch<bf16_t>(x_f32, rows, cols, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, s);
+    return EAVQA_E_DTYPE;
+}
+
+extern "C" int eavqa_layernorm_bwd(int dtype, int x_f32, int rows, int cols, const void* x, int64_t ldx,
+                                   const void* dy, int64_t lddy, const float* gamma, const float* mean,
+                                   const float* rstd, const float* dres, float* dx, int64_t lddx,
+                                   float* dgamma, float* dbeta, void* stream) {
+    if (!x || !dy || !dx || !mean || !rstd || rows <= 0 || cols <= 0) return EAVQA_E_ARG;
+    if (cols % 4) return EAVQA_E_SHAPE;
+    if (ldx % 4 || lddy % 4 || lddx % 4) return EAVQA_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32)
+        return ln_bwd_dispatch<float>(1, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta, s);
+    if (dtype == EAVQA_BF16)
+        return ln_bwd_dispatch<bf16_t>(x_f32, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta, s);
+    return EAVQA_E_DTYPE;
+}

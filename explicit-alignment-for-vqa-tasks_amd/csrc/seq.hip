@@ -1,0 +1,297 @@
+// Sequence assembly: the integer / index work around the LM (bit-exact against the oracle) and
+// the HBM-bound gathers that build the residual stream.  One wavefront per batch row does the
+// prefix scans (sentinel counts, OPT position ids, first-pad / seen-<BOS> flags).
+#include "common.h"
+
+namespace {
+
+// inclusive scan over the 64 lanes of a wave
+__device__ __forceinline__ int wave_iscan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// positions from a mask row held in LDS: GPT-2 arange, OPT cumsum(mask)*mask - 1 + 2
+__device__ __forceinline__ void write_positions(const int* mrow, int S, int pos_mode, int32_t* pos_row) {
+    const int lane = threadIdx.x & 63;
+    int carry = 0;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const int mv = (s < S) ? mrow[s] : 0;
+        const int inc = wave_iscan(mv) + carry;
+        if (s < S) pos_row[s] = pos_mode == 0 ? s : (inc * mv - 1 + 2);
+        carry = __shfl(inc, 63, 64);
+    }
+}
+
+__global__ __launch_bounds__(64) void prefix_rows_kernel(int L, int T, const int64_t* tokens, const int64_t* qmask,
+                                                         int pos_mode, int32_t* src, int32_t* mask_out, int32_t* pos) {
+    extern __shared__ int lds_mask[];
+    const int b = blockIdx.x, S = L + T, lane = threadIdx.x;
+    for (int s = lane; s < S; s += 64) {
+        int sv, mv;
+        if (s < L) { sv = -(1 + b * L + s); mv = 1; }
+        else { sv = (int)tokens[(int64_t)b * T + (s - L)]; mv = qmask[(int64_t)b * T + (s - L)] != 0 ? 1 : 0; }
+        src[(int64_t)b * S + s] = sv;
+        mask_out[(int64_t)b * S + s] = mv;
+        lds_mask[s] = mv;
+    }
+    __syncthreads();
+    write_positions(lds_mask, S, pos_mode, pos + (int64_t)b * S);
+}
+
+__global__ __launch_bounds__(64) void fewshot_rows_kernel(int T, int L, int n_img, int64_t special, const int64_t* tokens,
+                                                          const int64_t* qmask, int pos_mode, int32_t* src,
+                                                          int32_t* mask_out, int32_t* pos, int32_t* status) {
+    extern __shared__ int lds_mask[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int T_out = T + (L - 1) * n_img;
+    // pad everything first: rows with too few sentinels leave a defined tail
+    for (int s = lane; s < T_out; s += 64) { src[(int64_t)b * T_out + s] = 0; lds_mask[s] = 0; }
+    __syncthreads();
+    int carry = 0;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        int64_t tok = 0;
+        int is_s = 0;
+        if (t < T) {
+            tok = tokens[(int64_t)b * T + t];
+            is_s = (tok <= special && tok > special - n_img) ? 1 : 0;
+        }
+        const int inc = wave_iscan(is_s) + carry;
+        const int before = inc - is_s;                  // sentinels strictly before t
+        if (t < T) {
+            const int o = t + before * (L - 1);
+            if (is_s) {
+                if (before < n_img) {
+                    for (int l = 0; l < L; ++l) {
+                        src[(int64_t)b * T_out + o + l] = -(1 + (b * n_img + before) * L + l);
+                        lds_mask[o + l] = 1;
+                    }
+                }
+            } else if (o < T_out) {
+                src[(int64_t)b * T_out + o] = (int)tok;
+                lds_mask[o] = qmask[(int64_t)b * T + t] != 0 ? 1 : 0;
+            }
+        }
+        carry = __shfl(inc, 63, 64);
+    }
+    __syncthreads();
+    if (lane == 0) status[b] = carry;
+    for (int s = lane; s < T_out; s += 64) mask_out[(int64_t)b * T_out + s] = lds_mask[s];
+    write_positions(lds_mask, T_out, pos_mode, pos + (int64_t)b * T_out);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_assemble_kernel(int E, const int32_t* src, const int32_t* pos,
+                                                             const T* wte, int64_t ld_wte, const T* prefix, int64_t ld_prefix,
+                                                             const T* wpe, int64_t ld_wpe, float* x, int64_t ldx) {
+    const int row = blockIdx.x;
+    const int sv = src[row];
+    const T* e = sv >= 0 ? wte + (int64_t)sv * ld_wte : prefix + (int64_t)(-sv - 1) * ld_prefix;
+    const T* pe = wpe ? wpe + (int64_t)pos[row] * ld_wpe : nullptr;
+    for (int c = threadIdx.x * 4; c < E; c += 256 * 4) {
+        float4 v = elem<T>::ld4(e + c);
+        if (pe) { const float4 w = elem<T>::ld4(pe + c); v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w; }
+        *reinterpret_cast<float4*>(x + (int64_t)row * ldx + c) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(int E, const int32_t* src, const float* dx, int64_t lddx,
+                                                                 T* dprefix, int64_t ld_dprefix) {
+    const int row = blockIdx.x;
+    const int sv = src[row];
+    if (sv >= 0) return;
+    T* d = dprefix + (int64_t)(-sv - 1) * ld_dprefix;
+    for (int c = threadIdx.x * 4; c < E; c += 256 * 4)
+        elem<T>::st4(d + c, *reinterpret_cast<const float4*>(dx + (int64_t)row * lddx + c));
+}
+
+// labels: one wave per row; flags via prefix scans
+__global__ __launch_bounds__(64) void labels_kernel(int mode, int T, int L, const int64_t* ids, int64_t pad, int64_t bos,
+                                                    int64_t* out) {
+    const int b = blockIdx.x, lane = threadIdx.x, S = L + T;
+    for (int s = lane; s < L; s += 64) out[(int64_t)b * S + s] = -100;
+    int pad_seen = 0, bos_seen = 0;  // inclusive counts carried across chunks
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const int64_t tok = t < T ? ids[(int64_t)b * T + t] : pad - 1;
+        const int is_pad = (t < T && tok == pad) ? 1 : 0;
+        const int is_bos = (t < T && tok == bos && !is_pad) ? 1 : 0;
+        const int pad_inc = wave_iscan(is_pad) + pad_seen;
+        const int bos_inc = wave_iscan(is_bos) + bos_seen;
+        if (t < T) {
+            int64_t lab;
+            if (mode == 1) {
+                lab = is_pad ? -100 : tok;
+            } else {
+                const int pads_before = pad_inc - is_pad;
+                const int bos_before = bos_inc - is_bos;
+                if (pads_before == 0) {                       // at or before the first pad
+                    if (is_pad) lab = pad;                    // first -100 restored to the pad (= eos) id
+                    else if (is_bos) lab = -100;
+                    else lab = bos_before > 0 ? tok : -100;   // answer tokens kept, question masked
+                } else {
+                    lab = is_pad ? -100 : tok;                // loop already broke: left as initialised
+                }
+            }
+            out[(int64_t)b * S + L + t] = lab;
+        }
+        pad_seen = __shfl(pad_inc, 63, 64);
+        bos_seen = __shfl(bos_inc, 63, 64);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_kernel(int img, int ps, int g, const float* px, T* out, int64_t ldp) {
+    const int row = blockIdx.x;                // b*g*g + gy*g + gx
+    const int b = row / (g * g), cell = row - b * g * g, gy = cell / g, gx = cell - gy * g;
+    const int kreal = 3 * ps * ps;
+    for (int c = threadIdx.x; c < ldp; c += 256) {
+        float v = 0.f;
+        if (c < kreal) {
+            const int ch = c / (ps * ps), rem = c - ch * ps * ps, i = rem / ps, j = rem - i * ps;
+            v = px[(((int64_t)b * 3 + ch) * img + gy * ps + i) * img + gx * ps + j];
+        }
+        elem<T>::st(out + (int64_t)row * ldp + c, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void vit_assemble_kernel(int n_patch, int W, const T* pe, int64_t ldpe, const float* cls,
+                                                           const float* pos, float* x, int64_t ldx) {
+    const int row = blockIdx.x;                // b*(n_patch+1) + t
+    const int N = n_patch + 1;
+    const int b = row / N, t = row - b * N;
+    for (int c = threadIdx.x * 4; c < W; c += 256 * 4) {
+        float4 v = t == 0 ? *reinterpret_cast<const float4*>(cls + c)
+                          : elem<T>::ld4(pe + ((int64_t)b * n_patch + (t - 1)) * ldpe + c);
+        const float4 w = *reinterpret_cast<const float4*>(pos + (int64_t)t * W + c);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        *reinterpret_cast<float4*>(x + (int64_t)row * ldx + c) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_rows_kernel(int cols, const float* x, int64_t ldx, T* y, int64_t ldy) {
+    const int row = blockIdx.x;
+    for (int c = threadIdx.x * 4; c < cols; c += 256 * 4)
+        elem<T>::st4(y + (int64_t)row * ldy + c, *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + c));
+}
+
+}  // namespace
+
+extern "C" int eavqa_build_prefix_rows(int B, int L, int T, const int64_t* tokens, const int64_t* question_mask,
+                                       int pos_mode, int32_t* src, int32_t* mask_out, int32_t* pos, void* stream) {
+    if (B <= 0 || L < 0 || T < 0 || L + T <= 0 || !src || !mask_out || !pos) return EAVQA_E_ARG;
+    if (T > 0 && (!tokens || !question_mask)) return EAVQA_E_ARG;
+    if ((size_t)(L + T) * 4 > 60 * 1024) return EAVQA_E_SHAPE;
+    hipLaunchKernelGGL(prefix_rows_kernel, dim3(B), dim3(64), (size_t)(L + T) * 4, reinterpret_cast<hipStream_t>(stream),
+                       L, T, tokens, question_mask, pos_mode, src, mask_out, pos);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_build_fewshot_rows(int B, int T, int L, int n_img, int64_t special_token_id, const int64_t* tokens,
+                                        const int64_t* question_mask, int pos_mode, int32_t* src, int32_t* mask_out,
+                                        int32_t* pos, int32_t* status, void* stream) {
+    if (B <= 0 || T <= 0 || L <= 0 || n_img <= 0 || !tokens || !question_mask || !src || !mask_out || !pos || !status)
+        return EAVQA_E_ARG;
+    const size_t T_out = (size_t)T + (size_t)(L - 1) * n_img;
+    if (T_out * 4 > 60 * 1024) return EAVQA_E_SHAPE;
+    hipLaunchKernelGGL(fewshot_rows_kernel, dim3(B), dim3(64), T_out * 4, reinterpret_cast<hipStream_t>(stream), T, L, n_img,
+                       special_token_id, tokens, question_mask, pos_mode, src, mask_out, pos, status);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_embed_assemble(int dtype, int rows, int E, const int32_t* src, const int32_t* pos, const void* wte,
+                                    int64_t ld_wte, const void* prefix_rows, int64_t ld_prefix, const void* wpe,
+                                    int64_t ld_wpe, float* x, int64_t ldx, void* stream) {
+    if (rows <= 0 || E <= 0 || !src || !wte || !x) return EAVQA_E_ARG;
+    if (wpe && !pos) return EAVQA_E_ARG;
+    if (E % 4 || ld_wte % 4 || ldx % 4 || (prefix_rows && ld_prefix % 4) || (wpe && ld_wpe % 4)) return EAVQA_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32)
+        hipLaunchKernelGGL(embed_assemble_kernel<float>, dim3(rows), dim3(256), 0, s, E, src, pos, (const float*)wte, ld_wte,
+                           (const float*)prefix_rows, ld_prefix, (const float*)wpe, ld_wpe, x, ldx);
+    else if (dtype == EAVQA_BF16)
+        hipLaunchKernelGGL(embed_assemble_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, E, src, pos, (const bf16_t*)wte, ld_wte,
+                           (const bf16_t*)prefix_rows, ld_prefix, (const bf16_t*)wpe, ld_wpe, x, ldx);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_embed_assemble_bwd(int dtype, int rows, int E, const int32_t* src, const float* dx, int64_t lddx,
+                                        void* dprefix, int64_t ld_dprefix, void* stream) {
+    if (rows <= 0 || E <= 0 || !src || !dx || !dprefix) return EAVQA_E_ARG;
+    if (E % 4 || lddx % 4 || ld_dprefix % 4) return EAVQA_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32)
+        hipLaunchKernelGGL(embed_assemble_bwd_kernel<float>, dim3(rows), dim3(256), 0, s, E, src, dx, lddx, (float*)dprefix, ld_dprefix);
+    else if (dtype == EAVQA_BF16)
+        hipLaunchKernelGGL(embed_assemble_bwd_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, E, src, dx, lddx, (bf16_t*)dprefix, ld_dprefix);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_build_labels(int mode, int B, int T, int L, const int64_t* input_ids, int64_t pad_token_id,
+                                  int64_t bos_token_id, int64_t* labels_out, void* stream) {
+    if (B <= 0 || T <= 0 || L < 0 || !input_ids || !labels_out) return EAVQA_E_ARG;
+    if (mode != 0 && mode != 1) return EAVQA_E_ARG;
+    hipLaunchKernelGGL(labels_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), mode, T, L, input_ids,
+                       pad_token_id, bos_token_id, labels_out);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_patchify(int dtype, int B, int img, int ps, const float* pixels, void* patches, int64_t ldp, void* stream) {
+    if (B <= 0 || img <= 0 || ps <= 0 || !pixels || !patches) return EAVQA_E_ARG;
+    if (img % ps) return EAVQA_E_SHAPE;
+    if (ldp < 3 * ps * ps) return EAVQA_E_ARG;
+    const int g = img / ps;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32)
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(B * g * g), dim3(256), 0, s, img, ps, g, pixels, (float*)patches, ldp);
+    else if (dtype == EAVQA_BF16)
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(B * g * g), dim3(256), 0, s, img, ps, g, pixels, (bf16_t*)patches, ldp);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_vit_assemble(int dtype, int B, int n_patch, int W, const void* patch_embed, int64_t ldpe,
+                                  const float* cls, const float* pos, float* x, int64_t ldx, void* stream) {
+    if (B <= 0 || n_patch <= 0 || W <= 0 || !patch_embed || !cls || !pos || !x) return EAVQA_E_ARG;
+    if (W % 4 || ldpe % 4 || ldx % 4) return EAVQA_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rows = B * (n_patch + 1);
+    if (dtype == EAVQA_F32)
+        hipLaunchKernelGGL(vit_assemble_kernel<float>, dim3(rows), dim3(256), 0, s, n_patch, W, (const float*)patch_embed, ldpe, cls, pos, x, ldx);
+    else if (dtype == EAVQA_BF16)
+        hipLaunchKernelGGL(vit_assemble_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, n_patch, W, (const bf16_t*)patch_embed, ldpe, cls, pos, x, ldx);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_cast_rows(int dtype, int rows, int cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream) {
+    if (rows <= 0 || cols <= 0 || !x || !y) return EAVQA_E_ARG;
+    if (cols % 4 || ldx % 4 || ldy % 4) return EAVQA_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32)
+        hipLaunchKernelGGL(cast_rows_kernel<float>, dim3(rows), dim3(256), 0, s, cols, x, ldx, (float*)y, ldy);
+    else if (dtype == EAVQA_BF16)
+        hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, cols, x, ldx, (bf16_t*)y, ldy);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}

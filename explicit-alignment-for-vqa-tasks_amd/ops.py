@@ -1,0 +1,241 @@
+"""Tensor-level wrappers over the C ABI (include/eavqa.h).
+
+PyTorch supplies device memory and the current HIP stream; every arithmetic op on the hot path
+is one of the calls below.  Nothing here computes with torch ops on the data path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import ACT, BF16, F32, call
+
+Tensor = torch.Tensor
+
+
+def dtype_id(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return F32
+    if dt == torch.bfloat16:
+        return BF16
+    raise _lib.EavqaError(f"unsupported storage dtype {dt}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t: Tensor) -> None:
+    if not t.is_cuda:
+        raise _lib.EavqaError("eavqa ops run on the GPU only (no CPU fallback): got a CPU tensor")
+
+
+def _ld(t: Tensor) -> int:
+    """Leading dimension of a 2-D (or flattened row-major) tensor whose last dim is contiguous."""
+    if t.stride(-1) != 1 and t.shape[-1] != 1:
+        raise _lib.EavqaError("last dimension must be contiguous")
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+def gemm(a: Tensor, b: Tensor, *, a_kc: bool = True, b_kc: bool = True, bias: Optional[Tensor] = None,
+         act: str = "none", aux_in: Optional[Tensor] = None, aux_out: Optional[Tensor] = None,
+         residual: Optional[Tensor] = None, out: Optional[Tensor] = None, out_f32: bool = False,
+         alpha: float = 1.0) -> Tensor:
+    """``C = epilogue(alpha * A @ B^T)`` - see eavqa_gemm.  ``a``: [M,K] (a_kc) or [K,M];
+    ``b``: [N,K] (b_kc, nn.Linear layout) or [K,N] (Conv1D layout)."""
+    _dev(a)
+    M, K = (a.shape if a_kc else (a.shape[1], a.shape[0]))
+    N, Kb = (b.shape if b_kc else (b.shape[1], b.shape[0]))
+    if K != Kb:
+        raise _lib.EavqaError(f"gemm inner dims differ: {K} vs {Kb}")
+    if a.dtype != b.dtype:
+        raise _lib.EavqaError("gemm operands must share a dtype")
+    dt = dtype_id(a.dtype)
+    if out is None:
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
+    elif out.dtype != torch.float32 and out.dtype != a.dtype:
+        raise _lib.EavqaError("gemm out dtype must be float32 or the operand dtype")
+    out_f32 = out.dtype == torch.float32
+    aux = aux_in if aux_in is not None else aux_out
+    call("eavqa_gemm", dt, int(a_kc), int(b_kc), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out),
+         int(out_f32), float(alpha), _p(bias), ACT[act], _p(aux_in), _p(aux_out), _ld(aux) if aux is not None else 0,
+         _p(residual), _ld(residual) if residual is not None else 0, _stream())
+    return out
+
+
+def layernorm_fwd(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float, out_dtype: torch.dtype,
+                  save_stats: bool = False, out: Optional[Tensor] = None):
+    """Rows of ``x`` ([rows, cols], float32 or ``out_dtype``) -> ``y`` in ``out_dtype`` (+ mean, rstd)."""
+    _dev(x)
+    rows, cols = x.shape
+    y = out if out is not None else torch.empty((rows, cols), device=x.device, dtype=out_dtype)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    call("eavqa_layernorm_fwd", dtype_id(out_dtype), int(x.dtype == torch.float32), rows, cols, _p(x), _ld(x),
+         _p(gamma), _p(beta), float(eps), _p(y), _ld(y), _p(mean), _p(rstd), _stream())
+    return (y, mean, rstd) if save_stats else y
+
+
+def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], mean: Tensor, rstd: Tensor,
+                  dres: Optional[Tensor] = None, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
+                  out: Optional[Tensor] = None) -> Tensor:
+    _dev(x)
+    rows, cols = x.shape
+    dx = out if out is not None else torch.empty((rows, cols), device=x.device, dtype=torch.float32)
+    if dres is not None and _ld(dres) != _ld(dx):
+        raise _lib.EavqaError("dres must share dx's leading dimension")
+    call("eavqa_layernorm_bwd", dtype_id(dy.dtype), int(x.dtype == torch.float32), rows, cols, _p(x), _ld(x), _p(dy), _ld(dy),
+         _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _ld(dx), _p(dgamma), _p(dbeta), _stream())
+    return dx
+
+
+def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, H: int, Sq: int, Sk: int, hd: int, *,
+                  key_mask: Optional[Tensor] = None, causal: bool = False, scale: float = 1.0, save_lse: bool = False,
+                  q_batch_rows: int = 0, kv_batch_rows: int = 0, out: Optional[Tensor] = None):
+    """``q``: rows [B*Sq, >=H*hd] views (element (b,s,h,d) at row b*Sq+s, col h*hd+d); same for k/v."""
+    _dev(q)
+    o = out if out is not None else torch.empty((B * Sq, H * hd), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32) if save_lse else None
+    call("eavqa_attention_fwd", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o),
+         q_batch_rows, kv_batch_rows, _p(key_mask), int(causal), float(scale), _p(lse), _stream())
+    return (o, lse) if save_lse else o
+
+
+def attention_bwd(q, k, v, o, d_o, lse, B, H, Sq, Sk, hd, *, key_mask=None, causal=False, scale=1.0,
+                  dq=None, dk=None, dv=None):
+    _dev(q)
+    dq = dq if dq is not None else torch.empty((B * Sq, H * hd), device=q.device, dtype=q.dtype)
+    dk = dk if dk is not None else torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
+    dv = dv if dv is not None else torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
+    delta = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
+    call("eavqa_attention_bwd", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o),
+         _p(d_o), _ld(d_o), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(key_mask), int(causal), float(scale),
+         _p(lse), _p(delta), _stream())
+    return dq, dk, dv
+
+
+def build_prefix_rows(tokens: Tensor, question_mask: Tensor, L: int, pos_mode: int):
+    """int64 [B,T] tokens/mask -> (src, mask, pos) int32 [B, L+T]."""
+    _dev(tokens)
+    B, T = tokens.shape
+    tokens = tokens.contiguous()
+    qm = question_mask.to(torch.int64).contiguous()
+    S = L + T
+    src = torch.empty((B, S), device=tokens.device, dtype=torch.int32)
+    msk = torch.empty_like(src)
+    pos = torch.empty_like(src)
+    call("eavqa_build_prefix_rows", B, L, T, _p(tokens), _p(qm), pos_mode, _p(src), _p(msk), _p(pos), _stream())
+    return src, msk, pos
+
+
+def build_fewshot_rows(tokens: Tensor, question_mask: Tensor, L: int, n_img: int, special_token_id: int, pos_mode: int):
+    _dev(tokens)
+    B, T = tokens.shape
+    tokens = tokens.contiguous()
+    qm = question_mask.to(torch.int64).contiguous()
+    T_out = T + (L - 1) * n_img
+    src = torch.empty((B, T_out), device=tokens.device, dtype=torch.int32)
+    msk = torch.empty_like(src)
+    pos = torch.empty_like(src)
+    status = torch.empty(B, device=tokens.device, dtype=torch.int32)
+    call("eavqa_build_fewshot_rows", B, T, L, n_img, int(special_token_id), _p(tokens), _p(qm), pos_mode, _p(src), _p(msk),
+         _p(pos), _p(status), _stream())
+    return src, msk, pos, status
+
+
+def embed_assemble(src: Tensor, pos: Optional[Tensor], wte: Tensor, prefix_rows: Optional[Tensor], wpe: Optional[Tensor],
+                   out: Optional[Tensor] = None) -> Tensor:
+    _dev(src)
+    rows = src.numel()
+    E = wte.shape[1]
+    x = out if out is not None else torch.empty((rows, E), device=src.device, dtype=torch.float32)
+    call("eavqa_embed_assemble", dtype_id(wte.dtype), rows, E, _p(src), _p(pos), _p(wte), _ld(wte), _p(prefix_rows),
+         _ld(prefix_rows) if prefix_rows is not None else 0, _p(wpe), _ld(wpe) if wpe is not None else 0, _p(x), _ld(x), _stream())
+    return x
+
+
+def embed_assemble_bwd(src: Tensor, dx: Tensor, n_prefix_rows: int, dtype: torch.dtype) -> Tensor:
+    rows, E = dx.shape
+    d = torch.zeros((n_prefix_rows, E), device=dx.device, dtype=dtype)
+    call("eavqa_embed_assemble_bwd", dtype_id(dtype), rows, E, _p(src), _p(dx), _ld(dx), _p(d), _ld(d), _stream())
+    return d
+
+
+def build_labels(input_ids: Tensor, L: int, pad_token_id: int, bos_token_id: int = -1, mode: int = 0) -> Tensor:
+    _dev(input_ids)
+    B, T = input_ids.shape
+    ids = input_ids.contiguous()
+    out = torch.empty((B, L + T), device=ids.device, dtype=torch.int64)
+    call("eavqa_build_labels", mode, B, T, L, _p(ids), int(pad_token_id), int(bos_token_id), _p(out), _stream())
+    return out
+
+
+def ce_fwd(logits: Tensor, labels: Tensor, V: int):
+    """logits float32 [B*S, ld>=V]; labels int64 [B,S] unshifted -> (loss[1], count[1], row_lse)."""
+    _dev(logits)
+    B, S = labels.shape
+    rows = B * S
+    row_loss = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    row_lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    count = torch.empty(1, device=logits.device, dtype=torch.float32)
+    call("eavqa_ce_fwd", B, S, V, _p(logits), _ld(logits), _p(labels), _p(row_loss), _p(row_lse), _p(loss), _p(count), _stream())
+    return loss, count, row_lse
+
+
+def ce_bwd(logits: Tensor, labels: Tensor, V: int, row_lse: Tensor, count: Tensor, gscale: Tensor, dtype: torch.dtype,
+           ldd: int) -> Tensor:
+    B, S = labels.shape
+    d = torch.empty((B * S, ldd), device=logits.device, dtype=dtype)
+    call("eavqa_ce_bwd", dtype_id(dtype), B, S, V, _p(logits), _ld(logits), _p(labels), _p(row_lse), _p(count), _p(gscale),
+         _p(d), ldd, _stream())
+    return d
+
+
+def greedy_pick(logits: Tensor, V: int, pad_token_id: int, eos_token_id: Optional[int], raw: Tensor, emitted_col: Tensor,
+                unfinished: Tensor) -> None:
+    """``emitted_col``: int64 view [B] of column t of the [B, max_length] token matrix."""
+    B = logits.shape[0]
+    call("eavqa_greedy_pick", B, V, _p(logits), _ld(logits), int(pad_token_id if pad_token_id is not None else 0),
+         int(eos_token_id) if eos_token_id is not None else -1, _p(raw), _p(emitted_col), emitted_col.stride(0),
+         _p(unfinished), _stream())
+
+
+def adamw(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999,
+          eps: float = 1e-8, weight_decay: float = 0.01, grad_scale: float = 1.0, shadow: Optional[Tensor] = None) -> None:
+    _dev(param)
+    call("eavqa_adamw", param.numel(), _p(param), _p(grad), _p(m), _p(v), int(step), float(lr), float(beta1), float(beta2),
+         float(eps), float(weight_decay), float(grad_scale), dtype_id(shadow.dtype) if shadow is not None else 0, _p(shadow), _stream())
+
+
+def patchify(pixels: Tensor, ps: int, dtype: torch.dtype, ldp: int) -> Tensor:
+    _dev(pixels)
+    B, C3, img, _ = pixels.shape
+    g = img // ps
+    pixels = pixels.contiguous().float()
+    out = torch.empty((B * g * g, ldp), device=pixels.device, dtype=dtype)
+    call("eavqa_patchify", dtype_id(dtype), B, img, ps, _p(pixels), _p(out), ldp, _stream())
+    return out
+
+
+def vit_assemble(patch_embed: Tensor, cls: Tensor, pos: Tensor, B: int, n_patch: int) -> Tensor:
+    W = patch_embed.shape[1]
+    x = torch.empty((B * (n_patch + 1), W), device=patch_embed.device, dtype=torch.float32)
+    call("eavqa_vit_assemble", dtype_id(patch_embed.dtype), B, n_patch, W, _p(patch_embed), _ld(patch_embed), _p(cls), _p(pos),
+         _p(x), _ld(x), _stream())
+    return x
+
+
+def cast_rows(x: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Tensor:
+    rows, cols = x.shape
+    y = out if out is not None else torch.empty((rows, cols), device=x.device, dtype=dtype)
+    call("eavqa_cast_rows", dtype_id(dtype), rows, cols, _p(x), _ld(x), _p(y), _ld(y), _stream())
+    return y

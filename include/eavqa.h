@@ -1,0 +1,206 @@
+/*
+ * eavqa.h - C ABI of libeavqa_hip.so: the MI355X (gfx950) kernels behind the
+ * CLIP-ViT -> mapping network -> causal-LM hot path of
+ * rs-anderson/explicit-alignment-for-vqa-tasks.
+ *
+ * The reference has NO native code and no FFI: every entry point
+ * below replaces arithmetic the reference delegates to PyTorch / HuggingFace.
+ * Each declaration cites the reference (or third-party) code whose arithmetic it
+ * performs.  Paths are relative to the reference repo; "HF:" means
+ * transformers/ (5.15.0 in the build container, 4.12.5 pinned by the reference).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    named host_*; the caller owns and allocates every buffer;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*):
+ *    no allocation, no synchronisation, no global mutable state, so calls are
+ *    re-entrant across streams and capturable into a hipGraph;
+ *  - return value: 0 on success, a negative EAVQA_E_* code otherwise; nothing
+ *    throws across the ABI; eavqa_strerror() names a code;
+ *  - dtype: 0 = float32, 1 = bfloat16 (storage of activations / weights);
+ *    accumulation is always float32;
+ *  - "ld*" arguments are leading dimensions in ELEMENTS.
+ */
+#ifndef EAVQA_H
+#define EAVQA_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EAVQA_ABI_VERSION 1
+
+enum { EAVQA_F32 = 0, EAVQA_BF16 = 1 };
+
+/* activation ids (HF:activations.py: gelu_new :59-66, quick_gelu :117-123; torch tanh/relu) */
+enum { EAVQA_ACT_NONE = 0, EAVQA_ACT_TANH = 1, EAVQA_ACT_RELU = 2, EAVQA_ACT_GELU_NEW = 3, EAVQA_ACT_QUICK_GELU = 4 };
+
+enum {
+    EAVQA_OK = 0,
+    EAVQA_E_ARG = -1,       /* null pointer / non-positive size */
+    EAVQA_E_ALIGN = -2,     /* pointer or leading dimension not aligned as required */
+    EAVQA_E_SHAPE = -3,     /* shape not supported by the kernel */
+    EAVQA_E_DTYPE = -4,     /* unknown dtype / activation id */
+    EAVQA_E_LAUNCH = -5,    /* hipLaunch / hipFuncSetAttribute failed */
+    EAVQA_E_ARCH = -6       /* device is not gfx950 */
+};
+
+int eavqa_abi_version(void);
+const char* eavqa_strerror(int code);
+/* 0 when the current device is gfx950, EAVQA_E_ARCH otherwise (host call, no stream). */
+int eavqa_check_device(void);
+
+/* ---------------------------------------------------------------- GEMM ---
+ * C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )
+ *   a_kc != 0: A stored [M,K] (k contiguous, lda = row stride); else stored [K,M].
+ *   b_kc != 0: B stored [N,K] (k contiguous, torch.nn.Linear weight layout); else
+ *              stored [K,N] (HF Conv1D weight layout, HF:pytorch_utils.py Conv1D).
+ * epilogue, in this order:
+ *   v  = alpha*acc + bias[n]                 (bias: float32 [N] or NULL)
+ *   if aux_out: aux_out[m,n] = v             (pre-activation, dtype = `dtype`)
+ *   v  = act(v)                              (act id above)
+ *   if aux_in:  v = v * act'(aux_in[m,n])    (backward of the activation; act() above is skipped)
+ *   if residual: v += residual[m,n]          (float32, leading dim ldr; may alias C when out_f32)
+ *   C[m,n] = v                               (float32 when out_f32 != 0, else `dtype`)
+ * Replaces: torch.nn.Linear / HF Conv1D matmuls of clipcap.py:31-42 (MLP mapper),
+ * :45-104 (mapper transformer), HF:models/gpt2/modeling_gpt2.py:186-226,229-243,698,
+ * HF:models/opt/modeling_opt.py:137-181,228-248, HF:models/clip/modeling_clip.py:296-385,
+ * and their autograd (dgrad for frozen weights, dgrad+wgrad for the mapper).
+ * Requirements: contiguous dimension of A and of B a multiple of 8 (bf16) / 4 (f32)
+ * elements, 16-byte aligned base pointers, lda/ldb multiples of the same.
+ */
+int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
+               const void* A, int64_t lda, const void* B, int64_t ldb,
+               void* C, int64_t ldc, int out_f32, float alpha,
+               const float* bias, int act,
+               const void* aux_in, void* aux_out, int64_t ld_aux,
+               const float* residual, int64_t ldr, void* stream);
+
+/* ----------------------------------------------------------- LayerNorm ---
+ * torch.nn.LayerNorm over the last dim (ln_1/ln_2/ln_f HF:gpt2 :253-257,620;
+ * self_attn_layer_norm/final_layer_norm HF:opt :196-205; CLIP layer_norm1/2, pre/post
+ * HF:clip :340-343,909-912; mapper norm1/norm2 clipcap.py:131-135).
+ * x: float32 when x_f32 != 0 else `dtype`; y: `dtype`.  mean/rstd (float32 [rows]) may be
+ * NULL in inference.  gamma/beta float32 [cols].  cols % 4 == 0, cols <= 8192.
+ */
+int eavqa_layernorm_fwd(int dtype, int x_f32, int rows, int cols, const void* x, int64_t ldx,
+                        const float* gamma, const float* beta, float eps,
+                        void* y, int64_t ldy, float* mean, float* rstd, void* stream);
+/* dx[r,:] = (dres ? dres[r,:] : 0) + LayerNorm'(dy)[r,:]   (float32 out; dres may alias dx)
+ * dgamma/dbeta: float32 [cols], ACCUMULATED with atomics when non-NULL (mapper only). */
+int eavqa_layernorm_bwd(int dtype, int x_f32, int rows, int cols, const void* x, int64_t ldx,
+                        const void* dy, int64_t lddy, const float* gamma,
+                        const float* mean, const float* rstd,
+                        const float* dres, float* dx, int64_t lddx,
+                        float* dgamma, float* dbeta, void* stream);
+
+/* ----------------------------------------------------------- attention ---
+ * softmax(scale * q k^T + mask) v per (batch, head); eager formula
+ * HF:models/gpt2/modeling_gpt2.py:54-72 (causal + key padding), HF:clip :249-277 (full),
+ * clipcap.py:94-100 (mapper, layout bnmh == per-head softmax over keys).
+ * q/k/v/o: `dtype`, element (b, s, h, d) at base[(b*batch_rows + s)*ld + h*hd + d] where
+ * batch_rows is q_batch_rows for q/o and kv_batch_rows for k/v (0 = Sq / Sk; a KV cache
+ * allocated [B, S_max, E] passes kv_batch_rows = S_max).
+ * key_mask: int32 [B,Sk] (0 = padded key) or NULL.  causal: key j visible to query i iff
+ * j <= i + (Sk - Sq).  Masked scores are replaced by -FLT_MAX (HF adds finfo.min), so a
+ * fully masked row yields the uniform average over all Sk keys, never NaN.
+ * lse: float32 [B,H,Sq] log-sum-exp of the scaled masked scores (NULL in inference).
+ * hd in {4,8,16,32,48,64,80,96,128,160,256,320,512}.
+ */
+int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,
+                        const void* q, int64_t ldq, const void* k, int64_t ldk,
+                        const void* v, int64_t ldv, void* o, int64_t ldo,
+                        int64_t q_batch_rows, int64_t kv_batch_rows,
+                        const int32_t* key_mask, int causal, float scale, float* lse, void* stream);
+/* Backward (dense batches only: batch_rows = Sq / Sk): dq/dk/dv in `dtype`, addressed as q/k/v
+ * with leading dims lddq/lddk/lddv.
+ * delta: float32 scratch [B,H,Sq] (rowsum(do*o), written by the call). */
+int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int hd,
+                        const void* q, int64_t ldq, const void* k, int64_t ldk,
+                        const void* v, int64_t ldv, const void* o, int64_t ldo,
+                        const void* d_o, int64_t lddo,
+                        void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                        const int32_t* key_mask, int causal, float scale,
+                        const float* lse, float* delta, void* stream);
+
+/* ---------------------------------------- sequence assembly (indexing) ---
+ * Integer / index work is bit-exact against the oracle.
+ */
+/* ClipCaptionModel.forward/generate clipcap.py:303-321,353-381: row b of the LM input is
+ * [L prefix slots | T text tokens].  Writes src[b,s] = -(1 + b*L + s) for s < L (prefix row of
+ * image b), else token id; mask_out[b,s] = 1 for s < L else question_mask; pos[b,s] = s
+ * (pos_mode 0, GPT-2 HF:gpt2 :571-574) or cumsum(mask)*mask - 1 + 2 (pos_mode 1, OPT HF:opt :45-70).
+ * tokens/question_mask int64 [B,T] (the reference hands over int64); outputs int32 [B,L+T]. */
+int eavqa_build_prefix_rows(int B, int L, int T, const int64_t* tokens, const int64_t* question_mask,
+                            int pos_mode, int32_t* src, int32_t* mask_out, int32_t* pos, void* stream);
+/* VCT0Model.insert_prefix_into_input src/models/vct0.py:494-533 (golden vectors
+ * src/models/vct0_test.py:79-211): the n-th sentinel token of row b (ids special_token_id - i,
+ * i = 0..n_img-1) expands into the L prefix slots of image n.  T_out = T + (L-1)*n_img.
+ * Writes src (token id, or -(1 + (b*n_img + n)*L + l)), mask_out, pos (as above) and
+ * status[b] = number of sentinels found (caller checks == n_img; the reference's .view fails). */
+int eavqa_build_fewshot_rows(int B, int T, int L, int n_img, int64_t special_token_id,
+                             const int64_t* tokens, const int64_t* question_mask, int pos_mode,
+                             int32_t* src, int32_t* mask_out, int32_t* pos, int32_t* status, void* stream);
+/* x[b,s,:] = (src >= 0 ? wte[src] : prefix_rows[-src-1]) + wpe[pos]   (float32 out, residual stream)
+ * wte/wpe/prefix_rows in `dtype`; wpe may be NULL.  Also the append path of
+ * _generate_from_embeddings clipcap.py:423,440-442.  E % 4 == 0. */
+int eavqa_embed_assemble(int dtype, int rows, int E, const int32_t* src, const int32_t* pos,
+                         const void* wte, int64_t ld_wte, const void* prefix_rows, int64_t ld_prefix,
+                         const void* wpe, int64_t ld_wpe, float* x, int64_t ldx, void* stream);
+/* backward of the above w.r.t. prefix_rows: dprefix[-src-1,:] = dx[row,:] for src < 0 (`dtype` out). */
+int eavqa_embed_assemble_bwd(int dtype, int rows, int E, const int32_t* src, const float* dx, int64_t lddx,
+                             void* dprefix, int64_t ld_dprefix, void* stream);
+
+/* ClipCapExecutor.training_step label construction src/trainers/clipcap_exector.py:134-150
+ * (mode 0) and the Conceptual-Captions collate data_loader_conceptual_captions.py:94-95 (mode 1).
+ * Output int64 [B, L + T]: L leading -100 (clipcap.py:323-335) then the masked labels. */
+int eavqa_build_labels(int mode, int B, int T, int L, const int64_t* input_ids, int64_t pad_token_id,
+                       int64_t bos_token_id, int64_t* labels_out, void* stream);
+
+/* -------------------------------------------------------- loss / argmax ---
+ * ForCausalLMLoss HF:loss/loss_utils.py:49-71: labels shifted left by one, ignore_index -100,
+ * mean over kept positions.  logits float32 [rows, ld] (first V columns valid), labels int64 [B,S]
+ * UNshifted (rows = B*S, row r = b*S+s is scored against labels[b, s+1]).
+ * Writes row_loss/row_lse float32 [rows] (0 for ignored rows), then loss[0] = sum/count and
+ * count[0] (deterministic tree reduction, no atomics). */
+int eavqa_ce_fwd(int B, int S, int V, const float* logits, int64_t ld, const int64_t* labels,
+                 float* row_loss, float* row_lse, float* loss, float* count, void* stream);
+/* dlogits[r, v] = gscale[0] / count[0] * (softmax(logits[r])[v] - [v == label]) for kept rows, 0 for
+ * ignored rows and for pad columns V..ldd-1 (`dtype` out). */
+int eavqa_ce_bwd(int dtype, int B, int S, int V, const float* logits, int64_t ld, const int64_t* labels,
+                 const float* row_lse, const float* count, const float* gscale,
+                 void* dlogits, int64_t ldd, void* stream);
+/* torch.argmax(logits[:, -1, :], -1) clipcap.py:420-421 (first maximal index) fused with the
+ * finished-row bookkeeping of :426-461: raw[b] = argmax; emitted[b] = unfinished ? raw : pad;
+ * unfinished[b] &= (emitted != eos) when eos >= 0.  logits float32 [B, ld]. */
+int eavqa_greedy_pick(int B, int V, const float* logits, int64_t ld, int64_t pad_token_id, int64_t eos_token_id,
+                      int32_t* raw, int64_t* emitted, int64_t ld_emitted, int32_t* unfinished, void* stream);
+
+/* ----------------------------------------------------------- optimiser ---
+ * torch.optim.AdamW single-tensor update as configured at src/trainers/clipcap_exector.py:79-81
+ * over one flat float32 parameter buffer; grad_scale multiplies the gradient first
+ * (1/accumulate_grad_batches, 1/world_size).  shadow: optional `dtype` copy of the updated
+ * parameters for the next forward.  step >= 1. */
+int eavqa_adamw(int64_t n, float* param, const float* grad, float* m, float* v, int step,
+                float lr, float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                int shadow_dtype, void* shadow, void* stream);
+
+/* ------------------------------------------------------- CLIP patchify ---
+ * CLIPVisionEmbeddings HF:models/clip/modeling_clip.py:202-219: the stride==kernel conv is a GEMM
+ * over non-overlapping patches.  pixels float32 NCHW [B,3,img,img] -> patches `dtype`
+ * [B*g*g, ldp] with column (c*ps + i)*ps + j, zero-filled up to ldp (ldp >= 3*ps*ps). */
+int eavqa_patchify(int dtype, int B, int img, int ps, const float* pixels, void* patches, int64_t ldp, void* stream);
+/* x[b,0,:] = cls + pos[0]; x[b,1+t,:] = patch_embed[b*g*g+t,:] + pos[1+t]   (float32 out).
+ * patch_embed `dtype` [B*n_patch, ldpe]; cls/pos float32. */
+int eavqa_vit_assemble(int dtype, int B, int n_patch, int W, const void* patch_embed, int64_t ldpe,
+                       const float* cls, const float* pos, float* x, int64_t ldx, void* stream);
+
+/* float32 -> `dtype` elementwise copy with row strides (casts the residual stream / pooled rows). */
+int eavqa_cast_rows(int dtype, int rows, int cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAVQA_H */

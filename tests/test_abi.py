@@ -1,0 +1,67 @@
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/eavqa.h declares.
+No compute call is made here (there is no GPU in the build container)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "eavqa.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(eavqa_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from eavqa_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def test_header_declares_the_expected_surface():
+    syms = declared_symbols()
+    assert "eavqa_gemm" in syms and "eavqa_attention_fwd" in syms and len(syms) >= 20
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from eavqa_amd import _lib
+    for name in declared_symbols():
+        assert hasattr(lib, name), f"{name} declared in eavqa.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_abi_version_and_strerror(lib):
+    assert lib.eavqa_abi_version() == 1
+    assert lib.eavqa_strerror(0) == b"ok"
+    assert b"aligned" in lib.eavqa_strerror(-2)
+    assert b"unknown" in lib.eavqa_strerror(-99)
+
+
+def test_argument_validation_happens_before_any_launch(lib):
+    """Bad arguments are rejected on the host (no GPU needed): null pointers, bad dtype, bad shapes."""
+    assert lib.eavqa_gemm(1, 1, 1, 8, 8, 8, None, 8, None, 8, None, 8, 0, 1.0, None, 0, None, None, 0, None, 0, None) == -1
+    assert lib.eavqa_gemm(7, 1, 1, 8, 8, 8, 16, 8, 16, 8, 16, 8, 0, 1.0, None, 0, None, None, 0, None, 0, None) == -4
+    assert lib.eavqa_gemm(1, 1, 1, 8, 8, 12, 16, 16, 16, 16, 16, 8, 0, 1.0, None, 0, None, None, 0, None, 0, None) == -3
+    assert lib.eavqa_gemm(1, 1, 1, 8, 8, 8, 18, 8, 16, 8, 16, 8, 0, 1.0, None, 0, None, None, 0, None, 0, None) == -2
+    assert lib.eavqa_layernorm_fwd(0, 1, 4, 6, 16, 8, None, None, 1e-5, 16, 8, None, None, None) == -3
+    assert lib.eavqa_attention_fwd(0, 1, 1, 4, 4, 6, 16, 8, 16, 8, 16, 8, 16, 8, 0, 0, None, 0, 1.0, None, None) == -3
+    assert lib.eavqa_adamw(0, None, None, None, None, 1, 0.1, 0.9, 0.999, 1e-8, 0.01, 1.0, 0, None, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from eavqa_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.EavqaError, match="only compute path"):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected_not_emulated():
+    import torch
+    from eavqa_amd import ops, _lib
+    with pytest.raises(_lib.EavqaError, match="no CPU fallback"):
+        ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))

@@ -1,0 +1,427 @@
+"""GPU: every C-ABI kernel against a plain torch fp32/fp64 CPU computation of the same op.
+
+Tolerances (stated per test): the float32 path uses exact-fp32 MFMA / VALU arithmetic and must
+agree with an fp64-accumulated reference to ~1e-5 relative; the bfloat16 path stores operands and
+outputs in bf16 (8 significant bits) with fp32 accumulation, so it is compared against the same
+reference computed from the bf16-rounded inputs with a tolerance of a few bf16 ulps of the output
+scale.  Integer / index kernels are bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from conftest import load_golden
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from eavqa_amd import ops as _ops, _lib
+    assert _lib.load().eavqa_check_device() == 0, "not a gfx950 device"
+    return _ops
+
+
+DEV = "cuda"
+
+
+def rnd(*shape, dtype=torch.float32, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def tol(dtype, scale=1.0):
+    return (2e-5 if dtype == torch.float32 else 2e-2) * scale
+
+
+ACTS = {
+    "none": lambda x: x, "tanh": torch.tanh, "relu": torch.relu, "gelu_new": oracle.gelu_new, "quick_gelu": oracle.quick_gelu,
+}
+
+
+# --------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (1, 8, 8), (64, 520, 1032), (300, 50257 // 64, 128)])
+def test_gemm_layouts_and_edges(ops, dtype, a_kc, b_kc, M, N, K):
+    vec = 8 if dtype == torch.bfloat16 else 4
+    if (not a_kc and M % vec) or (not b_kc and N % vec):
+        pytest.skip("contiguous dim must be a multiple of the vector width (checked in test_gemm_rejects)")
+    a = rnd(M, K, dtype=dtype, seed=1)
+    b = rnd(N, K, dtype=dtype, seed=2)   # asymmetric random operands
+    ref = (a.double() @ b.double().T).float()
+    A = (a if a_kc else a.T.contiguous()).to(DEV)
+    Bm = (b if b_kc else b.T.contiguous()).to(DEV)
+    out = ops.gemm(A, Bm, a_kc=a_kc, b_kc=b_kc, out_f32=True)
+    torch.cuda.synchronize()
+    err = (out.cpu() - ref).abs().max().item()
+    assert err <= (1e-4 if dtype == torch.float32 else 1e-3) * math.sqrt(K), err  # fp32 accumulate of exact products
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_identity_asymmetric(ops, dtype):
+    """A = I with an asymmetric B catches a transposed C write (guide section 3)."""
+    n = 128
+    a = torch.eye(n, dtype=dtype)
+    b = (torch.arange(n)[:, None] * 3 + torch.arange(n)[None, :] * 0.5).to(dtype)  # B[n][k]
+    out = ops.gemm(a.to(DEV), b.to(DEV), out_f32=True).cpu()
+    assert torch.equal(out, b.float().T)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["none", "tanh", "relu", "gelu_new", "quick_gelu"])
+def test_gemm_epilogue_forward(ops, dtype, act):
+    M, N, K = 150, 264, 96
+    a, b = rnd(M, K, dtype=dtype, seed=3, scale=0.3), rnd(N, K, dtype=dtype, seed=4, scale=0.3)
+    bias = rnd(N, seed=5)
+    res = rnd(M, N, seed=6)
+    pre = (a.double() @ b.double().T).float() * 0.5 + bias
+    ref = ACTS[act](pre) + res
+    aux = torch.empty(M, N, dtype=dtype, device=DEV)
+    out = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=act, aux_out=aux, residual=res.to(DEV), out_f32=True, alpha=0.5)
+    assert (out.cpu() - ref).abs().max().item() <= tol(dtype, 0.1 if dtype == torch.float32 else 1.0)
+    assert (aux.float().cpu() - pre).abs().max().item() <= tol(dtype, 1.0)
+    # storage-dtype output, no residual
+    out2 = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act=act)
+    assert out2.dtype == dtype
+    assert (out2.float().cpu() - ACTS[act]((a.double() @ b.double().T).float() + bias)).abs().max().item() <= tol(dtype, 2.0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["tanh", "relu", "gelu_new", "quick_gelu"])
+def test_gemm_epilogue_activation_backward(ops, dtype, act):
+    M, N, K = 70, 136, 64
+    a, b = rnd(M, K, dtype=dtype, seed=7, scale=0.3), rnd(N, K, dtype=dtype, seed=8, scale=0.3)
+    u = rnd(M, N, dtype=dtype, seed=9)
+    uu = u.float().clone().requires_grad_(True)
+    ACTS[act](uu).sum().backward()
+    ref = (a.double() @ b.double().T).float() * uu.grad
+    out = ops.gemm(a.to(DEV), b.to(DEV), act=act, aux_in=u.to(DEV), out_f32=True)
+    assert (out.cpu() - ref).abs().max().item() <= tol(dtype, 0.2)
+
+
+def test_gemm_residual_alias_accumulates(ops):
+    """wgrad accumulation: residual aliases the float32 output."""
+    a, b = rnd(64, 32, seed=1), rnd(40, 32, seed=2)
+    acc = rnd(64, 40, seed=3).to(DEV)
+    ref = acc.cpu() + a @ b.T
+    ops.gemm(a.to(DEV), b.to(DEV), residual=acc, out=acc)
+    assert torch.allclose(acc.cpu(), ref, atol=1e-5)
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from eavqa_amd._lib import EavqaError
+    a = torch.zeros(16, 12, device=DEV, dtype=torch.bfloat16)   # K = 12 not a multiple of 8
+    b = torch.zeros(16, 12, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(EavqaError):
+        ops.gemm(a, b)
+    with pytest.raises(EavqaError):
+        ops.gemm(torch.zeros(4, 8), torch.zeros(4, 8))          # CPU tensors: no fallback
+
+
+def test_gemm_large_bf16_statistical(ops):
+    """A real-shape bf16 GEMM (GPT-2-large c_fc on one batch): relative Frobenius error vs fp64."""
+    M, N, K = 2688, 5120, 1280
+    a, b = rnd(M, K, dtype=torch.bfloat16, seed=11), rnd(N, K, dtype=torch.bfloat16, seed=12, scale=0.02)
+    out = ops.gemm(a.to(DEV), b.to(DEV), out_f32=True).cpu()
+    ref = (a.float() @ b.float().T)
+    rel = (out - ref).norm() / ref.norm()
+    assert rel < 1e-5, rel   # products exact in fp32, only summation order differs
+
+
+# --------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(5, 64), (37, 768), (130, 1280), (3, 4096), (2, 8192)])
+def test_layernorm_forward_backward(ops, dtype, rows, cols):
+    x = rnd(rows, cols, seed=1) * 2 + 0.5
+    g, b = rnd(cols, seed=2) * 0.2 + 1, rnd(cols, seed=3) * 0.1
+    dy = rnd(rows, cols, dtype=dtype, seed=4)
+    xx = x.clone().requires_grad_(True)
+    gg = g.clone().requires_grad_(True)
+    bb = b.clone().requires_grad_(True)
+    y_ref = torch.nn.functional.layer_norm(xx, (cols,), gg, bb, 1e-5)
+    y_ref.backward(dy.float())
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, dtype, save_stats=True)
+    assert (y.float().cpu() - y_ref.detach()).abs().max().item() <= (1e-5 if dtype == torch.float32 else 3e-2)
+    assert torch.allclose(mean.cpu(), x.mean(-1), atol=1e-5)
+    if cols > 4096:
+        return  # backward supports cols <= 4096 (documented)
+    dres = rnd(rows, cols, seed=5)
+    dgamma = torch.zeros(cols, device=DEV)
+    dbeta = torch.zeros(cols, device=DEV)
+    dx = ops.layernorm_bwd(x.to(DEV), dy.to(DEV), g.to(DEV), mean, rstd, dres=dres.to(DEV), dgamma=dgamma, dbeta=dbeta)
+    assert (dx.cpu() - (dres + xx.grad)).abs().max().item() <= 2e-5 * max(1.0, xx.grad.abs().max().item())
+    assert torch.allclose(dgamma.cpu(), gg.grad, atol=1e-4, rtol=1e-4)
+    assert torch.allclose(dbeta.cpu(), bb.grad, atol=1e-4, rtol=1e-4)
+
+
+def test_layernorm_bf16_input_rows_with_stride(ops):
+    x = rnd(9, 256, dtype=torch.bfloat16, seed=1).to(DEV)
+    view = x[:, :128]    # ld = 256, cols = 128
+    y = ops.layernorm_fwd(view, None, None, 1e-5, torch.bfloat16)
+    ref = torch.nn.functional.layer_norm(view.float().cpu(), (128,))
+    assert (y.float().cpu() - ref).abs().max().item() <= 3e-2
+
+
+# --------------------------------------------------------------------------- attention
+def attn_ref(q, k, v, key_mask, causal, scale):
+    """q [B,Sq,H,hd] etc. float64 reference with the oracle's masking (finfo.min add)."""
+    B, Sq, H, hd = q.shape
+    Sk = k.shape[1]
+    s = torch.einsum("bihd,bjhd->bhij", q, k) * scale
+    keep = torch.ones(B, 1, Sq, Sk, dtype=torch.bool)
+    if key_mask is not None:
+        keep = keep & (key_mask != 0)[:, None, None, :]
+    if causal:
+        i = torch.arange(Sq)[:, None]
+        j = torch.arange(Sk)[None, :]
+        keep = keep & (j <= i + (Sk - Sq))[None, None]
+    s = torch.where(keep, s, torch.full_like(s, torch.finfo(torch.float32).min))
+    p = torch.softmax(s, dim=-1)
+    return torch.einsum("bhij,bjhd->bihd", p, v)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Sq,Sk,hd,causal,masked", [
+    (2, 3, 42, 42, 64, True, True),      # LM shape, ragged right padding
+    (1, 2, 50, 50, 64, False, False),    # ViT-B/32
+    (2, 2, 150, 150, 80, True, True),    # few-shot prompt, OPT-2.7B head dim
+    (1, 1, 130, 130, 128, True, False),  # > 2 key tiles
+    (2, 8, 7, 7, 8, False, False),       # mapper transformer (tiny)
+    (1, 2, 20, 20, 96, False, False),    # mapper on GPT-2 (E/8 = 96)
+    (2, 2, 1, 33, 64, True, True),       # decode step against a cache
+    (1, 1, 9, 9, 160, False, False),
+    (1, 4, 257, 257, 64, False, False),  # ViT-L/14
+])
+def test_attention_forward_backward(ops, dtype, B, H, Sq, Sk, hd, causal, masked):
+    E = H * hd
+    q, k, v = (rnd(B, Sq, H, hd, dtype=dtype, seed=1), rnd(B, Sk, H, hd, dtype=dtype, seed=2), rnd(B, Sk, H, hd, dtype=dtype, seed=3))
+    do = rnd(B, Sq, H, hd, dtype=dtype, seed=4)
+    km = None
+    if masked:
+        lens = torch.tensor([Sk - 3 * i - 1 for i in range(B)]).clamp(min=1)
+        km = (torch.arange(Sk)[None] < lens[:, None]).int()
+    scale = hd ** -0.5
+    qq, kk, vv = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    ref = attn_ref(qq, kk, vv, km, causal, scale)
+    ref.backward(do.double())
+    # packed qkv rows like the LM's c_attn output: [B*S, 3E] when Sq == Sk
+    if Sq == Sk:
+        qkv = torch.cat([q.reshape(B * Sq, E), k.reshape(B * Sk, E), v.reshape(B * Sk, E)], dim=1).to(DEV)
+        Q, K, V = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+    else:
+        Q, K, V = q.reshape(B * Sq, E).to(DEV), k.reshape(B * Sk, E).to(DEV), v.reshape(B * Sk, E).to(DEV)
+    kmd = km.to(DEV) if km is not None else None
+    o, lse = ops.attention_fwd(Q, K, V, B, H, Sq, Sk, hd, key_mask=kmd, causal=causal, scale=scale, save_lse=True)
+    t = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (o.float().cpu().reshape(B, Sq, H, hd) - ref.detach().float()).abs().max().item() <= t
+    dq, dk, dv = ops.attention_bwd(Q, K, V, o, do.reshape(B * Sq, E).to(DEV), lse, B, H, Sq, Sk, hd, key_mask=kmd, causal=causal, scale=scale)
+    tb = 5e-5 if dtype == torch.float32 else 6e-2
+    for got, want in ((dq, qq.grad), (dk, kk.grad), (dv, vv.grad)):
+        assert (got.float().cpu().reshape(want.shape) - want.float()).abs().max().item() <= tb * max(1.0, want.abs().max().item())
+
+
+def test_attention_fully_masked_row_is_finite(ops):
+    B, H, S, hd = 1, 1, 5, 16
+    q = rnd(B * S, H * hd, seed=1).to(DEV)
+    km = torch.zeros(B, S, dtype=torch.int32, device=DEV)
+    o = ops.attention_fwd(q, q, q, B, H, S, S, hd, key_mask=km, causal=False, scale=1.0)
+    assert torch.isfinite(o).all()
+    assert torch.allclose(o.cpu(), q.cpu().mean(0, keepdim=True).expand(S, -1), atol=1e-5)  # uniform average
+
+
+def test_attention_kv_cache_batch_stride(ops):
+    B, H, hd, Smax, t = 2, 2, 64, 16, 11
+    E = H * hd
+    cache_k, cache_v = rnd(B, Smax, E, seed=1).to(DEV), rnd(B, Smax, E, seed=2).to(DEV)
+    q = rnd(B, 1, E, seed=3).to(DEV)
+    o = ops.attention_fwd(q.view(B, E), cache_k.view(B * Smax, E), cache_v.view(B * Smax, E), B, H, 1, t, hd,
+                          causal=True, scale=hd ** -0.5, kv_batch_rows=Smax)
+    ref = attn_ref(q.cpu().double().view(B, 1, H, hd), cache_k.cpu().double()[:, :t].reshape(B, t, H, hd),
+                   cache_v.cpu().double()[:, :t].reshape(B, t, H, hd), None, True, hd ** -0.5)
+    assert (o.cpu().view(B, 1, H, hd) - ref.float()).abs().max().item() <= 1e-5
+
+
+# --------------------------------------------------------------------------- sequence assembly (bit-exact)
+@pytest.mark.parametrize("pos_mode", [0, 1])
+def test_build_prefix_rows_exact(ops, pos_mode):
+    g = torch.Generator().manual_seed(3)
+    B, T, L = 5, 70, 10
+    tok = torch.randint(0, 50257, (B, T), generator=g)
+    lens = torch.tensor([70, 1, 33, 64, 65])
+    qm = (torch.arange(T)[None] < lens[:, None]).long()
+    src, msk, pos = ops.build_prefix_rows(tok.to(DEV), qm.to(DEV), L, pos_mode)
+    S = L + T
+    exp_src = torch.cat([-(1 + torch.arange(B * L).view(B, L)), tok], dim=1).int()
+    exp_msk = torch.cat([torch.ones(B, L, dtype=torch.long), qm], dim=1)
+    assert torch.equal(src.cpu(), exp_src)
+    assert torch.equal(msk.cpu().long(), exp_msk)
+    if pos_mode == 0:   # HF:gpt2 :571-574
+        exp_pos = torch.arange(S).expand(B, S)
+    else:               # HF:opt :45-70
+        exp_pos = (torch.cumsum(exp_msk, 1) * exp_msk - 1) + 2
+    assert torch.equal(pos.cpu().long(), exp_pos)
+
+
+@pytest.mark.parametrize("case", ["z", "f", "s"])
+def test_build_fewshot_rows_and_embed_match_reference(ops, case):
+    """insert_prefix_into_input: golden vectors from vct0_test.py and the reference's own output."""
+    z = load_golden("insert_prefix.npz")
+    if case == "s":
+        L, E, shots = [int(v) for v in z["s_cfg"]]
+    else:
+        L, E, shots = 2, 3, (0 if case == "z" else 2)
+    tok = torch.from_numpy(z[f"{case}_tok"])
+    qm = torch.from_numpy(z[f"{case}_mask"])
+    text = torch.from_numpy(z[f"{case}_text"])
+    pp = torch.from_numpy(z[f"{case}_pp"])
+    B, T = tok.shape
+    src, msk, pos, status = ops.build_fewshot_rows(tok.to(DEV), qm.to(DEV), L, shots + 1, 32099, 0)
+    assert status.cpu().tolist() == [shots + 1] * B
+    assert torch.equal(msk.cpu().long(), torch.from_numpy(z[f"{case}_out_mask"]))
+    # the embedding gather itself: fake vocabulary = per-position text embeddings (E padded to 4)
+    Ep = 8
+    wte = torch.zeros(B * T, Ep)
+    wte[:, :E] = text.reshape(B * T, E)
+    # remap token ids to their flat (b,t) index so wte[id] is that position's embedding
+    flat_ids = torch.arange(B * T).view(B, T)
+    is_sent = (tok <= 32099) & (tok > 32099 - (shots + 1))
+    tok2 = torch.where(is_sent, tok, flat_ids + 40000)   # keep sentinels, move text ids out of the way
+    src2, _, _, _ = ops.build_fewshot_rows(tok2.to(DEV), qm.to(DEV), L, shots + 1, 32099, 0)
+    src2 = torch.where(src2 >= 0, src2 - 40000, src2)
+    prefix = torch.zeros(B * (shots + 1) * L, Ep)
+    prefix[:, :E] = pp.reshape(-1, E)
+    x = ops.embed_assemble(src2.contiguous(), None, wte.to(DEV), prefix.to(DEV), None)
+    got = x.cpu().view(B, -1, Ep)[:, :, :E]
+    assert torch.equal(got, torch.from_numpy(z[f"{case}_emb"]))
+
+
+def test_build_fewshot_rows_reports_wrong_sentinel_count(ops):
+    tok = torch.tensor([[32099, 5, 6, 7], [5, 6, 7, 8]])
+    qm = torch.ones_like(tok)
+    _, _, _, status = ops.build_fewshot_rows(tok.to(DEV), qm.to(DEV), 3, 1, 32099, 0)
+    assert status.cpu().tolist() == [1, 0]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_assemble_and_backward(ops, dtype):
+    g = torch.Generator().manual_seed(1)
+    B, L, T, E, V = 3, 4, 9, 64, 100
+    wte, wpe = rnd(V, E, dtype=dtype, seed=1), rnd(32, E, dtype=dtype, seed=2)
+    prefix = rnd(B * L, E, dtype=dtype, seed=3)
+    tok = torch.randint(0, V, (B, T), generator=g)
+    qm = torch.ones(B, T, dtype=torch.long)
+    src, msk, pos = ops.build_prefix_rows(tok.to(DEV), qm.to(DEV), L, 0)
+    x = ops.embed_assemble(src, pos, wte.to(DEV), prefix.to(DEV), wpe.to(DEV))
+    ref = torch.cat([prefix.view(B, L, E).float(), wte.float()[tok]], dim=1) + wpe.float()[: L + T][None]
+    assert torch.equal(x.cpu().view(B, L + T, E), ref)
+    dx = rnd(B * (L + T), E, seed=4)
+    dp = ops.embed_assemble_bwd(src, dx.to(DEV), B * L, dtype)
+    assert torch.equal(dp.float().cpu().view(B, L, E), dx.view(B, L + T, E)[:, :L].to(dtype).float())
+
+
+def test_build_labels_exact(ops):
+    z = load_golden("label_mask.npz")
+    ids = torch.from_numpy(z["input_ids"])
+    pad, bos = int(z["pad_id"]), int(z["bos_id"])
+    out = ops.build_labels(ids.to(DEV), 3, pad, bos, mode=0).cpu()
+    assert torch.equal(out[:, :3], torch.full((ids.shape[0], 3), -100))
+    assert out[:, 3:].tolist() == z["labels"].tolist()
+    # random rows (longer than one wave) against the oracle's loop-for-loop restatement
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(0, 12, (16, 150), generator=g)
+    ids[3, 100:] = pad
+    ids[4] = pad
+    ids[5, :] = 3
+    for mode, want in ((0, oracle.label_mask_vqa(ids, pad, bos)), (1, oracle.label_mask_cc(ids, pad))):
+        got = ops.build_labels(ids.to(DEV), 0, pad, bos, mode=mode).cpu()
+        assert torch.equal(got, want)
+
+
+# --------------------------------------------------------------------------- loss / pick
+@pytest.mark.parametrize("V,ld", [(50257, 50264), (320, 320), (7, 8)])
+def test_cross_entropy_forward_backward(ops, V, ld):
+    B, S = 3, 11
+    logits = torch.zeros(B * S, ld)
+    logits[:, :V] = rnd(B * S, V, seed=1) * 3
+    g = torch.Generator().manual_seed(2)
+    labels = torch.randint(0, V, (B, S), generator=g)
+    labels[0, :4] = -100
+    labels[2, 7:] = -100
+    lg = logits[:, :V].view(B, S, V).clone().requires_grad_(True)
+    ref = oracle.causal_lm_loss(lg, labels)
+    ref.backward()
+    loss, count, row_lse = ops.ce_fwd(logits.to(DEV), labels.to(DEV), V)
+    assert abs(loss.item() - ref.item()) <= 1e-5 * max(1.0, abs(ref.item()))
+    gs = torch.ones(1, device=DEV)
+    d = ops.ce_bwd(logits.to(DEV), labels.to(DEV), V, row_lse, count, gs, torch.float32, ld)
+    assert torch.allclose(d.cpu()[:, :V].view(B, S, V), lg.grad, atol=1e-7)
+    assert (d.cpu()[:, V:] == 0).all()
+    db = ops.ce_bwd(logits.to(DEV), labels.to(DEV), V, row_lse, count, gs, torch.bfloat16, ld)
+    assert torch.allclose(db.float().cpu()[:, :V].view(B, S, V), lg.grad, atol=1e-3, rtol=1e-2)
+
+
+def test_cross_entropy_all_ignored_is_nan_like_torch(ops):
+    logits = rnd(4, 8, seed=1).to(DEV)
+    labels = torch.full((2, 2), -100).to(DEV)
+    loss, count, _ = ops.ce_fwd(logits, labels, 8)
+    assert count.item() == 0 and math.isnan(loss.item())
+
+
+def test_greedy_pick_first_max_and_finished_rows(ops):
+    V, ld, B = 1000, 1000, 4
+    logits = rnd(B, ld, seed=1)
+    logits[0, 17] = 50.0
+    logits[0, 900] = 50.0          # tie: first index wins (torch.argmax)
+    logits[1, 999] = 60.0
+    logits[2, 5] = 70.0
+    logits[3, 0] = 80.0
+    raw = torch.empty(B, dtype=torch.int32, device=DEV)
+    toks = torch.zeros(B, 6, dtype=torch.int64, device=DEV)
+    unf = torch.tensor([1, 1, 0, 1], dtype=torch.int32, device=DEV)
+    ops.greedy_pick(logits.to(DEV), V, 42, 999, raw, toks[:, 2], unf)
+    assert raw.cpu().tolist() == [17, 999, 5, 0]
+    assert toks[:, 2].cpu().tolist() == [17, 999, 42, 0]     # finished row emits pad (clipcap.py:431-434)
+    assert unf.cpu().tolist() == [1, 0, 0, 1]                # row 1 just produced eos (clipcap.py:458-461)
+    ops.greedy_pick(logits.to(DEV), V, 42, None, raw, toks[:, 3], unf)   # eos None: raw tokens, flags untouched
+    assert toks[:, 3].cpu().tolist() == [17, 999, 5, 0] and unf.cpu().tolist() == [1, 0, 0, 1]
+
+
+# --------------------------------------------------------------------------- optimiser
+@pytest.mark.parametrize("n", [4096, 1003])
+def test_adamw_matches_torch(ops, n):
+    p = rnd(n, seed=1)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-3)
+    P, M, Vv = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    for step in range(1, 5):
+        g = rnd(n, seed=10 + step)
+        ref.grad = g.clone() * 0.5
+        opt.step()
+        ops.adamw(P, g.to(DEV), M, Vv, step, 1e-3, grad_scale=0.5, shadow=shadow)
+    assert torch.allclose(P.cpu(), ref.detach(), atol=2e-7, rtol=1e-6)
+    assert torch.equal(shadow.cpu(), P.cpu().to(torch.bfloat16))
+
+
+# --------------------------------------------------------------------------- ViT front end
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("img,ps", [(64, 32), (42, 14)])
+def test_patchify_and_vit_assemble(ops, dtype, img, ps):
+    B, W = 2, 64
+    px = rnd(B, 3, img, img, seed=1)
+    g = img // ps
+    K = 3 * ps * ps
+    ldp = (K + 7) // 8 * 8
+    pt = ops.patchify(px.to(DEV), ps, dtype, ldp).cpu()
+    ref = px.reshape(B, 3, g, ps, g, ps).permute(0, 2, 4, 1, 3, 5).reshape(B * g * g, K)
+    assert torch.equal(pt[:, :K].float(), ref.to(dtype).float())
+    assert (pt[:, K:] == 0).all()
+    pe = rnd(B * g * g, W, dtype=dtype, seed=2)
+    cls, pos = rnd(W, seed=3), rnd(g * g + 1, W, seed=4)
+    x = ops.vit_assemble(pe.to(DEV), cls.to(DEV), pos.to(DEV), B, g * g).cpu().view(B, g * g + 1, W)
+    ref = torch.cat([cls.expand(B, 1, W), pe.float().view(B, g * g, W)], dim=1) + pos[None]
+    assert torch.equal(x, ref)
