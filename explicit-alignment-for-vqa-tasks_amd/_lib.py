@@ -26,11 +26,13 @@ SIGNATURES = {
     "eavqa_gemm": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i32, f32, ptr, i32, ptr, ptr, i64, ptr, i64, ptr],
     "eavqa_layernorm_fwd": [i32, i32, i32, i32, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, ptr, ptr],
     "eavqa_layernorm_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr],
-    "eavqa_attention_fwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i32, f32, ptr, ptr],
+    "eavqa_attention_fwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i64, i32, f32, ptr, ptr],
     "eavqa_attention_bwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64,
                             ptr, i64, ptr, i64, ptr, i64, ptr, i32, f32, ptr, ptr, ptr],
-    "eavqa_build_prefix_rows": [i32, i32, i32, ptr, ptr, i32, ptr, ptr, ptr, ptr],
+    "eavqa_build_prefix_rows": [i32, i32, i32, ptr, ptr, i32, i32, i32, ptr, ptr, ptr, ptr],
     "eavqa_build_fewshot_rows": [i32, i32, i32, i32, i64, ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr],
+    "eavqa_copy_rows": [i32, i32, i32, i32, ptr, i64, i64, ptr, i64, i64, i64, ptr],
+    "eavqa_colsum": [i32, i32, i32, ptr, i64, ptr, i32, ptr],
     "eavqa_embed_assemble": [i32, i32, i32, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr],
     "eavqa_embed_assemble_bwd": [i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr],
     "eavqa_build_labels": [i32, i32, i32, i32, ptr, i64, i64, ptr, ptr],

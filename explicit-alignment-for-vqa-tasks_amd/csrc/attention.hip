@@ -24,6 +24,7 @@ struct AttnParams {
     const int32_t* key_mask;
     float* lse; float* delta;
     int B, H, Sq, Sk, hd, causal, tile;
+    int64_t ld_mask;
     int64_t bsq, bsk;   // rows between consecutive batches of q/o/do/dq and of k/v/dk/dv
     float scale;
 };
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         stage_rows<T>(Ks, K, p.ldk, (int64_t)b * p.bsk, k0, p.Sk, p.tile, p.hd, head_off);
         stage_rows<T>(Vs, V, p.ldv, (int64_t)b * p.bsk, k0, p.Sk, p.tile, p.hd, head_off);
         for (int c = threadIdx.x; c < p.tile; c += blockDim.x)
-            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.Sk + k0 + c] != 0);
+            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
         __syncthreads();
         const int nkeys = min(p.tile, p.Sk - k0);
         for (int c0 = 0; c0 < nkeys; c0 += CK) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         stage_rows<T>(Ks, K, p.ldk, (int64_t)b * p.bsk, k0, p.Sk, p.tile, p.hd, head_off);
         stage_rows<T>(Vs, V, p.ldv, (int64_t)b * p.bsk, k0, p.Sk, p.tile, p.hd, head_off);
         for (int c = threadIdx.x; c < p.tile; c += blockDim.x)
-            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.Sk + k0 + c] != 0);
+            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
         __syncthreads();
         const int nkeys = min(p.tile, p.Sk - k0);
         for (int j = 0; j < nkeys; ++j) {
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         dk[d] = make_float4(0.f, 0.f, 0.f, 0.f);
         dv[d] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const bool kvalid = active && (!p.key_mask || p.key_mask[(int64_t)b * p.Sk + j] != 0);
+    const bool kvalid = active && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + j] != 0);
 
     // first query any key of this block is visible to: i >= j - off
     int q_begin = 0;
@@ -378,7 +379,7 @@ extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int 
                                    const void* q, int64_t ldq, const void* k, int64_t ldk,
                                    const void* v, int64_t ldv, void* o, int64_t ldo,
                                    int64_t q_batch_rows, int64_t kv_batch_rows,
-                                   const int32_t* key_mask, int causal, float scale, float* lse, void* stream) {
+                                   const int32_t* key_mask, int64_t ld_mask, int causal, float scale, float* lse, void* stream) {
     if (!q || !k || !v || !o) return EAVQA_E_ARG;
     int rc = check_common(dtype, B, H, Sq, Sk, hd);
     if (rc) return rc;
@@ -387,6 +388,8 @@ extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int 
     p.q = q; p.k = k; p.v = v; p.out = o; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.key_mask = key_mask; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.hd = hd;
     p.causal = causal; p.scale = scale;
+    p.ld_mask = ld_mask > 0 ? ld_mask : Sk;
+    if (p.ld_mask < Sk) return EAVQA_E_ARG;
     p.bsq = q_batch_rows > 0 ? q_batch_rows : Sq;
     p.bsk = kv_batch_rows > 0 ? kv_batch_rows : Sk;
     if (p.bsq < Sq || p.bsk < Sk) return EAVQA_E_ARG;
@@ -410,7 +413,7 @@ extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int 
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.key_mask = key_mask; p.lse = const_cast<float*>(lse); p.delta = delta;
     p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.hd = hd; p.causal = causal; p.scale = scale;
-    p.bsq = Sq; p.bsk = Sk;
+    p.bsq = Sq; p.bsk = Sk; p.ld_mask = Sk;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = dtype == EAVQA_F32 ? dispatch<float>(K_DQ, p, s) : dispatch<bf16_t>(K_DQ, p, s);
     if (rc) return rc;

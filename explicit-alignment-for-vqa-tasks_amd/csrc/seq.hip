@@ -30,12 +30,13 @@ __device__ __forceinline__ void write_positions(const int* mrow, int S, int pos_
 }
 
 __global__ __launch_bounds__(64) void prefix_rows_kernel(int L, int T, const int64_t* tokens, const int64_t* qmask,
-                                                         int pos_mode, int32_t* src, int32_t* mask_out, int32_t* pos) {
+                                                         int pos_mode, int pstride, int poff, int32_t* src,
+                                                         int32_t* mask_out, int32_t* pos) {
     extern __shared__ int lds_mask[];
     const int b = blockIdx.x, S = L + T, lane = threadIdx.x;
     for (int s = lane; s < S; s += 64) {
         int sv, mv;
-        if (s < L) { sv = -(1 + b * L + s); mv = 1; }
+        if (s < L) { sv = -(1 + b * pstride + poff + s); mv = 1; }
         else { sv = (int)tokens[(int64_t)b * T + (s - L)]; mv = qmask[(int64_t)b * T + (s - L)] != 0 ? 1 : 0; }
         src[(int64_t)b * S + s] = sv;
         mask_out[(int64_t)b * S + s] = mv;
@@ -185,15 +186,85 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(int cols, const float* x
         elem<T>::st4(y + (int64_t)row * ldy + c, *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + c));
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void copy_rows_kernel(int S, int cols, const T* src, int64_t lds, int64_t sbr, T* dst,
+                                                        int64_t ldd, int64_t dbr, int64_t drow0) {
+    const int row = blockIdx.x;               // b*S + s
+    const int b = row / S, s = row - b * S;
+    const T* x = src + ((int64_t)b * sbr + s) * lds;
+    T* y = dst + ((int64_t)b * dbr + drow0 + s) * ldd;
+    constexpr int V = 16 / sizeof(T);         // 16-byte vectors when cols allows, else 4 elements
+    if ((cols % V) == 0 && (lds % V) == 0 && (ldd % V) == 0) {
+        for (int c = threadIdx.x * V; c < cols; c += 256 * V)
+            *reinterpret_cast<uint4*>(y + c) = *reinterpret_cast<const uint4*>(x + c);
+    } else {
+        for (int c = threadIdx.x * 4; c < cols; c += 256 * 4) elem<T>::st4(y + c, elem<T>::ld4(x + c));
+    }
+}
+
+// column sums: block = 64 columns x 4 row-groups, rows strided over blockIdx.y, fp32 atomics between blocks
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(int rows, int cols, const T* x, int64_t ldx, float* out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = threadIdx.x >> 6;
+    float a = 0.f;
+    if (c < cols)
+        for (int r = blockIdx.y * 4 + rg; r < rows; r += gridDim.y * 4) a += elem<T>::ld(x + (int64_t)r * ldx + c);
+    part[rg][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rg == 0 && c < cols) {
+        const float t = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+        if (gridDim.y == 1) out[c] += t; else atomicAdd(out + c, t);
+    }
+}
+
+__global__ void zero_kernel(int n, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = 0.f;
+}
+
 }  // namespace
 
+extern "C" int eavqa_copy_rows(int dtype, int B, int S, int cols, const void* src, int64_t lds, int64_t src_batch_rows,
+                               void* dst, int64_t ldd, int64_t dst_batch_rows, int64_t dst_row0, void* stream) {
+    if (B <= 0 || S <= 0 || cols <= 0 || !src || !dst) return EAVQA_E_ARG;
+    if (cols % 4 || lds % 4 || ldd % 4) return EAVQA_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32)
+        hipLaunchKernelGGL(copy_rows_kernel<float>, dim3(B * S), dim3(256), 0, s, S, cols, (const float*)src, lds, src_batch_rows,
+                           (float*)dst, ldd, dst_batch_rows, dst_row0);
+    else if (dtype == EAVQA_BF16)
+        hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(B * S), dim3(256), 0, s, S, cols, (const bf16_t*)src, lds, src_batch_rows,
+                           (bf16_t*)dst, ldd, dst_batch_rows, dst_row0);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_colsum(int dtype, int rows, int cols, const void* x, int64_t ldx, float* out, int accumulate, void* stream) {
+    if (rows <= 0 || cols <= 0 || !x || !out) return EAVQA_E_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!accumulate) hipLaunchKernelGGL(zero_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, cols, out);
+    int gy = (rows + 255) / 256;          // ~64 rows per row-group per block
+    if (gy > 64) gy = 64;
+    dim3 grid((cols + 63) / 64, gy);
+    if (dtype == EAVQA_F32) hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, rows, cols, (const float*)x, ldx, out);
+    else if (dtype == EAVQA_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, rows, cols, (const bf16_t*)x, ldx, out);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
 extern "C" int eavqa_build_prefix_rows(int B, int L, int T, const int64_t* tokens, const int64_t* question_mask,
-                                       int pos_mode, int32_t* src, int32_t* mask_out, int32_t* pos, void* stream) {
+                                       int pos_mode, int prefix_row_stride, int prefix_row_offset,
+                                       int32_t* src, int32_t* mask_out, int32_t* pos, void* stream) {
     if (B <= 0 || L < 0 || T < 0 || L + T <= 0 || !src || !mask_out || !pos) return EAVQA_E_ARG;
+    if (prefix_row_stride < L || prefix_row_offset < 0) return EAVQA_E_ARG;
     if (T > 0 && (!tokens || !question_mask)) return EAVQA_E_ARG;
     if ((size_t)(L + T) * 4 > 60 * 1024) return EAVQA_E_SHAPE;
     hipLaunchKernelGGL(prefix_rows_kernel, dim3(B), dim3(64), (size_t)(L + T) * 4, reinterpret_cast<hipStream_t>(stream),
-                       L, T, tokens, question_mask, pos_mode, src, mask_out, pos);
+                       L, T, tokens, question_mask, pos_mode, prefix_row_stride, prefix_row_offset, src, mask_out, pos);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }

@@ -1,0 +1,130 @@
+"""CLIP vision tower (``model.encode_image``) executed by the HIP kernels.
+
+The reference calls OpenAI-CLIP's ``encode_image`` offline
+(src/tools/extract_clip_embeddings_conceptual_captions.py:83-88,
+src/tools/extract_contrastive_image_embeddings.py:59-63) and stores float32 ``[D]`` rows; this build
+runs the same arithmetic in the loop.  Weights use the HF ``CLIPVisionModelWithProjection`` key
+names (transformers/models/clip/modeling_clip.py:138-219 embeddings, :280-385 layers, :898-960 tower
++ projection; QuickGELU transformers/activations.py:117-123), which is the same graph as OpenAI's
+``VisionTransformer``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict
+
+import torch
+
+from .. import ops
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class ViTConfig:
+    width: int
+    n_layer: int
+    n_head: int
+    mlp: int
+    patch: int
+    image: int
+    proj: int
+    eps: float = 1e-5
+    act: str = "quick_gelu"
+
+    @property
+    def n_patch(self) -> int:
+        return (self.image // self.patch) ** 2
+
+
+KNOWN_VITS = {
+    "ViT-B/32": ViTConfig(768, 12, 12, 3072, 32, 224, 512),
+    "ViT-B/16": ViTConfig(768, 12, 12, 3072, 16, 224, 512),
+    "ViT-L/14": ViTConfig(1024, 24, 16, 4096, 14, 224, 768),
+    "ViT-L/14@336px": ViTConfig(1024, 24, 16, 4096, 14, 336, 768),
+}
+
+
+def random_init_vit_state_dict(cfg: ViTConfig, seed: int = 2021, device="cpu") -> Dict[str, Tensor]:
+    """Seeded random-init weights under HF key names (std 0.02-ish like HF's CLIP init; LayerNorm 1/0)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    W = cfg.width
+
+    def n(*shape, std=0.02):
+        return torch.randn(*shape, generator=g, device=device) * std
+
+    ones, zeros = (lambda k: torch.ones(k, device=device)), (lambda k: torch.zeros(k, device=device))
+    p = "vision_model."
+    sd = {
+        p + "embeddings.class_embedding": n(W, std=W ** -0.5),
+        p + "embeddings.patch_embedding.weight": n(W, 3, cfg.patch, cfg.patch),
+        p + "embeddings.position_embedding.weight": n(cfg.n_patch + 1, W),
+        p + "pre_layrnorm.weight": ones(W), p + "pre_layrnorm.bias": zeros(W),
+        p + "post_layernorm.weight": ones(W), p + "post_layernorm.bias": zeros(W),
+        "visual_projection.weight": n(cfg.proj, W, std=W ** -0.5),
+    }
+    for i in range(cfg.n_layer):
+        q = f"{p}encoder.layers.{i}."
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[q + f"self_attn.{nm}.weight"], sd[q + f"self_attn.{nm}.bias"] = n(W, W, std=W ** -0.5), zeros(W)
+        sd[q + "layer_norm1.weight"], sd[q + "layer_norm1.bias"] = ones(W), zeros(W)
+        sd[q + "layer_norm2.weight"], sd[q + "layer_norm2.bias"] = ones(W), zeros(W)
+        sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"] = n(cfg.mlp, W), zeros(cfg.mlp)
+        sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"] = n(W, cfg.mlp), zeros(W)
+    return sd
+
+
+class ClipVisionEncoder:
+    """Frozen CLIP ViT: ``encode_image(pixels [B,3,H,W] float32) -> float32 [B, D]``."""
+
+    def __init__(self, cfg: ViTConfig, state_dict: Dict[str, Tensor], dtype: torch.dtype = torch.bfloat16, device="cuda"):
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        T = lambda t: t.to(device=self.device, dtype=dtype).contiguous()
+        F = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
+        p = "vision_model."
+        W = cfg.width
+        K = 3 * cfg.patch * cfg.patch
+        self.kpad = (K + 7) // 8 * 8          # ViT-L/14: K = 588 -> 592 (zero columns contribute nothing)
+        wp = torch.zeros((W, self.kpad), dtype=torch.float32)
+        wp[:, :K] = state_dict[p + "embeddings.patch_embedding.weight"].reshape(W, K).float().cpu()
+        self.w_patch = T(wp)
+        self.cls = F(state_dict[p + "embeddings.class_embedding"])
+        self.pos = F(state_dict[p + "embeddings.position_embedding.weight"])
+        self.pre_g, self.pre_b = F(state_dict[p + "pre_layrnorm.weight"]), F(state_dict[p + "pre_layrnorm.bias"])
+        self.post_g, self.post_b = F(state_dict[p + "post_layernorm.weight"]), F(state_dict[p + "post_layernorm.bias"])
+        self.w_proj = T(state_dict["visual_projection.weight"])
+        self.layers = []
+        for i in range(cfg.n_layer):
+            q = f"{p}encoder.layers.{i}."
+            self.layers.append(dict(
+                ln1_g=F(state_dict[q + "layer_norm1.weight"]), ln1_b=F(state_dict[q + "layer_norm1.bias"]),
+                w_qkv=T(torch.cat([state_dict[q + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)),
+                b_qkv=F(torch.cat([state_dict[q + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)),
+                w_o=T(state_dict[q + "self_attn.out_proj.weight"]), b_o=F(state_dict[q + "self_attn.out_proj.bias"]),
+                ln2_g=F(state_dict[q + "layer_norm2.weight"]), ln2_b=F(state_dict[q + "layer_norm2.bias"]),
+                w_fc1=T(state_dict[q + "mlp.fc1.weight"]), b_fc1=F(state_dict[q + "mlp.fc1.bias"]),
+                w_fc2=T(state_dict[q + "mlp.fc2.weight"]), b_fc2=F(state_dict[q + "mlp.fc2.bias"]),
+            ))
+
+    @torch.no_grad()
+    def encode_image(self, pixels: Tensor) -> Tensor:
+        c, T = self.cfg, self.dtype
+        B = pixels.shape[0]
+        if pixels.shape[-1] != c.image or pixels.shape[-2] != c.image:
+            raise ValueError(f"Input image size ({pixels.shape[-2]}*{pixels.shape[-1]}) doesn't match model ({c.image}*{c.image}).")
+        W, H, N = c.width, c.n_head, c.n_patch + 1
+        hd = W // H
+        patches = ops.patchify(pixels.to(self.device), c.patch, T, self.kpad)
+        pe = ops.gemm(patches, self.w_patch)
+        x = ops.vit_assemble(pe, self.cls, self.pos, B, c.n_patch)
+        x = ops.layernorm_fwd(x, self.pre_g, self.pre_b, c.eps, torch.float32)     # the residual stream stays fp32
+        for L in self.layers:
+            a = ops.layernorm_fwd(x, L["ln1_g"], L["ln1_b"], c.eps, T)
+            qkv = ops.gemm(a, L["w_qkv"], bias=L["b_qkv"])
+            ctx = ops.attention_fwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], B, H, N, N, hd, causal=False, scale=hd ** -0.5)
+            x1 = ops.gemm(ctx, L["w_o"], bias=L["b_o"], residual=x, out_f32=True)
+            a2 = ops.layernorm_fwd(x1, L["ln2_g"], L["ln2_b"], c.eps, T)
+            f = ops.gemm(a2, L["w_fc1"], bias=L["b_fc1"], act=c.act)
+            x = ops.gemm(f, L["w_fc2"], bias=L["b_fc2"], residual=x1, out_f32=True)
+        pooled = ops.layernorm_fwd(x.view(B, N, W)[:, 0], self.post_g, self.post_b, c.eps, T)
+        return ops.gemm(pooled, self.w_proj, out_f32=True)

@@ -1,0 +1,95 @@
+"""Greedy generation for the prefix LM (``_generate_from_embeddings`` src/models/clipcap.py:387-471).
+
+Two drivers produce the same token ids:
+  * ``use_cache=False`` - the reference's algorithm verbatim: every step re-runs the whole, growing
+    sequence (clipcap.py:414-419);
+  * ``use_cache=True``  - prefill once, keep per-layer K/V in HBM ``[B, S_max, E]`` and run one
+    token per step; a decode step is weight-streaming (HBM) bound.
+Token bookkeeping (argmax, pad for finished rows, eos flags) is one kernel per step
+(``eavqa_greedy_pick``); the host reads the ``unfinished`` flags back once per step only to
+honour the reference's early exit (clipcap.py:463).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from .. import ops
+from .lm import FrozenCausalLM
+
+Tensor = torch.Tensor
+
+
+def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Tensor, pos: Tensor, B: int, S0: int,
+                  max_length: int, pad_token_id: Optional[int], eos_token_id: Optional[int], use_cache: bool = True) -> List[List[int]]:
+    """``src/mask/pos``: int32 [B, S0 + max_length] for the whole horizon (appended positions have mask 1;
+    their ``src`` entries are filled in as tokens are produced)."""
+    dev = lm.device
+    S_max = S0 + max_length
+    tokens = torch.zeros((B, max_length), dtype=torch.int64, device=dev)
+    raw = torch.empty(B, dtype=torch.int32, device=dev)
+    unfinished = torch.ones(B, dtype=torch.int32, device=dev)
+    produced = 0
+    if use_cache:
+        cache = _KVCache(lm, B, S_max)
+        logits = _prefill(lm, cache, prefix_rows, src[:, :S0].contiguous(), pos[:, :S0].contiguous(), mask, B, S0, S_max)
+    for t in range(max_length):
+        if not use_cache:
+            S = S0 + t
+            logits = lm.forward(prefix_rows, src[:, :S].contiguous(), pos[:, :S].contiguous(), mask[:, :S].contiguous(),
+                                B, S, logits="last")["logits"]
+        ops.greedy_pick(logits, lm.vocab, pad_token_id, eos_token_id, raw, tokens[:, t], unfinished)
+        produced = t + 1
+        src[:, S0 + t] = raw                                   # the RAW argmax is what gets embedded (clipcap.py:423)
+        if eos_token_id is not None and int(unfinished.max().item()) == 0:
+            break                                              # clipcap.py:463
+        if t + 1 < max_length and use_cache:
+            logits = _decode_step(lm, cache, raw, pos[:, S0 + t].contiguous(), mask, B, S0 + t, S_max)
+    return tokens[:, :produced].cpu().numpy().astype(int).tolist()   # clipcap.py:469
+
+
+class _KVCache:
+    def __init__(self, lm: FrozenCausalLM, B: int, S_max: int):
+        E = lm.cfg.n_embd
+        self.k = [torch.empty((B * S_max, E), device=lm.device, dtype=lm.dtype) for _ in lm.layers]
+        self.v = [torch.empty((B * S_max, E), device=lm.device, dtype=lm.dtype) for _ in lm.layers]
+
+
+def _block(lm: FrozenCausalLM, cache: _KVCache, x: Tensor, mask: Tensor, B: int, Sq: int, row0: int, S_max: int) -> Tensor:
+    """All decoder layers for ``Sq`` new positions per row starting at sequence index ``row0``;
+    K/V of the new positions are appended to the cache and attention runs against rows [0, row0+Sq)."""
+    c, T = lm.cfg, lm.dtype
+    E, H, hd = c.n_embd, c.n_head, c.head_dim
+    Sk = row0 + Sq
+    for li, L in enumerate(lm.layers):
+        a = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T)
+        qkv = ops.gemm(a, L.w_qkv, bias=L.b_qkv)
+        ops.copy_rows(qkv[:, E:2 * E], cache.k[li], B, Sq, E, Sq, S_max, row0)
+        ops.copy_rows(qkv[:, 2 * E:], cache.v[li], B, Sq, E, Sq, S_max, row0)
+        ctx = ops.attention_fwd(qkv[:, :E], cache.k[li], cache.v[li], B, H, Sq, Sk, hd, key_mask=mask, causal=True,
+                                scale=hd ** -0.5, kv_batch_rows=S_max, ld_mask=mask.stride(0))
+        x1 = ops.gemm(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True)
+        a2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T)
+        f = ops.gemm(a2, L.w_fc1, bias=L.b_fc1, act=c.act)
+        x = ops.gemm(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True)
+    return x
+
+
+def _last_logits(lm: FrozenCausalLM, x: Tensor, B: int, Sq: int) -> Tensor:
+    E = lm.cfg.n_embd
+    xl = x.view(B, Sq, E)[:, -1]
+    hf = ops.layernorm_fwd(xl, lm.lnf_g, lm.lnf_b, lm.cfg.eps, lm.dtype)
+    return lm._head(hf)
+
+
+def _prefill(lm, cache, prefix_rows, src, pos, mask, B, S0, S_max) -> Tensor:
+    x = ops.embed_assemble(src, pos, lm.wte, prefix_rows, lm.wpe)
+    x = _block(lm, cache, x, mask, B, S0, 0, S_max)
+    return _last_logits(lm, x, B, S0)
+
+
+def _decode_step(lm, cache, raw, pos_col, mask, B, row0, S_max) -> Tensor:
+    x = ops.embed_assemble(raw, pos_col, lm.wte, None, lm.wpe)
+    x = _block(lm, cache, x, mask, B, 1, row0, S_max)
+    return _last_logits(lm, x, B, 1)

@@ -1,0 +1,356 @@
+"""Frozen causal LM (GPT-2 / OPT) executed entirely by the HIP kernels.
+
+Arithmetic mirrored:
+  * GPT-2: HF ``GPT2LMHeadModel`` transformers/models/gpt2/modeling_gpt2.py:571-620 (positions =
+    arange, wpe add), :246-309 (pre-LN block), :75-226 (c_attn Conv1D ``[in,out]``, scale hd^-0.5,
+    causal + key-padding mask), :229-243 (gelu_new MLP), :698 (lm_head tied to wte);
+  * OPT: HF ``OPTForCausalLM`` transformers/models/opt/modeling_opt.py:45-70 (learned positions,
+    offset 2, ``cumsum(mask)*mask-1``), :97-181 (q scaled before q.k), :184-254 (pre-LN, ReLU),
+    :273-397 (final_layer_norm), :443-538 (lm_head);
+  * loss: transformers/loss/loss_utils.py:32-71 (shift, ignore -100, mean).
+
+The LM is frozen (``ClipCaptionPrefix.train`` clipcap.py:594-599), so the backward pass is dgrad
+only: no weight gradient and no GEMM input needs saving - only what LayerNorm, attention and the
+activation need.  Weights are pre-packed once at load into the k-contiguous layouts the MFMA GEMM
+streams fastest: a forward copy ``[N,K]`` and (lazily, for training) a backward copy ``[K,N]``;
+288 GB of HBM makes the second copy free.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from .. import ops
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class LMConfig:
+    arch: str            # "gpt2" | "opt"
+    n_layer: int
+    n_head: int
+    n_embd: int
+    ffn: int
+    vocab: int
+    n_pos: int           # number of learned positions (OPT: excluding the offset of 2)
+    eps: float = 1e-5
+    act: str = "gelu_new"
+    eos_token_id: Optional[int] = None
+    pad_token_id: Optional[int] = None
+
+    @property
+    def head_dim(self) -> int:
+        return self.n_embd // self.n_head
+
+    @property
+    def pos_mode(self) -> int:
+        return 0 if self.arch == "gpt2" else 1
+
+    @staticmethod
+    def from_hf_dict(d: dict) -> "LMConfig":
+        mt = d.get("model_type", "gpt2")
+        if mt == "gpt2":
+            E = d.get("n_embd", 768)
+            return LMConfig("gpt2", d.get("n_layer", 12), d.get("n_head", 12), E, d.get("n_inner") or 4 * E,
+                            d.get("vocab_size", 50257), d.get("n_positions", 1024), d.get("layer_norm_epsilon", 1e-5),
+                            d.get("activation_function", "gelu_new"), d.get("eos_token_id", 50256), d.get("pad_token_id"))
+        if mt == "opt":
+            E = d.get("hidden_size", 768)
+            if d.get("word_embed_proj_dim", E) != E or not d.get("do_layer_norm_before", True):
+                raise NotImplementedError("OPT-350m style project_in/out / post-LN is not on the hot path")
+            return LMConfig("opt", d.get("num_hidden_layers", 12), d.get("num_attention_heads", 12), E, d.get("ffn_dim", 3072),
+                            d.get("vocab_size", 50272), d.get("max_position_embeddings", 2048), 1e-5,
+                            d.get("activation_function", "relu"), d.get("eos_token_id", 2), d.get("pad_token_id", 1))
+        raise NotImplementedError(f"model_type {mt!r} is not a causal LM on the hot path")
+
+
+# named model shapes used by BASELINE.json configs (public architecture constants)
+KNOWN_CONFIGS = {
+    "gpt2": dict(model_type="gpt2", n_embd=768, n_layer=12, n_head=12, vocab_size=50257, n_positions=1024),
+    "gpt2-medium": dict(model_type="gpt2", n_embd=1024, n_layer=24, n_head=16, vocab_size=50257, n_positions=1024),
+    "gpt2-large": dict(model_type="gpt2", n_embd=1280, n_layer=36, n_head=20, vocab_size=50257, n_positions=1024),
+    "gpt2-xl": dict(model_type="gpt2", n_embd=1600, n_layer=48, n_head=25, vocab_size=50257, n_positions=1024),
+    "facebook/opt-125m": dict(model_type="opt", hidden_size=768, num_hidden_layers=12, num_attention_heads=12, ffn_dim=3072),
+    "facebook/opt-1.3b": dict(model_type="opt", hidden_size=2048, num_hidden_layers=24, num_attention_heads=32, ffn_dim=8192),
+    "facebook/opt-2.7b": dict(model_type="opt", hidden_size=2560, num_hidden_layers=32, num_attention_heads=32, ffn_dim=10240),
+    "facebook/opt-6.7b": dict(model_type="opt", hidden_size=4096, num_hidden_layers=32, num_attention_heads=32, ffn_dim=16384),
+}
+
+
+def random_init_state_dict(cfg: LMConfig, seed: int = 2021, device="cpu") -> Dict[str, Tensor]:
+    """Seeded random-init weights in HF key names / HF shapes (normal(0, 0.02), LayerNorm 1/0,
+    zero biases; GPT-2 c_proj scaled by 1/sqrt(2*n_layer) as HF ``_init_weights`` does).  Used for
+    synthetic benchmarks - there are no pretrained weights offline."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    E, F, V = cfg.n_embd, cfg.ffn, cfg.vocab
+
+    def n(*shape, std=0.02):
+        return torch.randn(*shape, generator=g, device=device) * std
+
+    sd: Dict[str, Tensor] = {}
+    ones, zeros = (lambda k: torch.ones(k, device=device)), (lambda k: torch.zeros(k, device=device))
+    if cfg.arch == "gpt2":
+        sd["transformer.wte.weight"] = n(V, E)
+        sd["transformer.wpe.weight"] = n(cfg.n_pos, E)
+        ps = 0.02 / math.sqrt(2 * cfg.n_layer)
+        for i in range(cfg.n_layer):
+            p = f"transformer.h.{i}."
+            sd[p + "ln_1.weight"], sd[p + "ln_1.bias"] = ones(E), zeros(E)
+            sd[p + "attn.c_attn.weight"], sd[p + "attn.c_attn.bias"] = n(E, 3 * E), zeros(3 * E)
+            sd[p + "attn.c_proj.weight"], sd[p + "attn.c_proj.bias"] = n(E, E, std=ps), zeros(E)
+            sd[p + "ln_2.weight"], sd[p + "ln_2.bias"] = ones(E), zeros(E)
+            sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = n(E, F), zeros(F)
+            sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = n(F, E, std=ps), zeros(E)
+        sd["transformer.ln_f.weight"], sd["transformer.ln_f.bias"] = ones(E), zeros(E)
+    else:
+        pre = "model.decoder."
+        sd[pre + "embed_tokens.weight"] = n(V, E)
+        sd[pre + "embed_positions.weight"] = n(cfg.n_pos + 2, E)
+        for i in range(cfg.n_layer):
+            p = f"{pre}layers.{i}."
+            for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                sd[p + f"self_attn.{nm}.weight"], sd[p + f"self_attn.{nm}.bias"] = n(E, E), zeros(E)
+            sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"] = ones(E), zeros(E)
+            sd[p + "fc1.weight"], sd[p + "fc1.bias"] = n(F, E), zeros(F)
+            sd[p + "fc2.weight"], sd[p + "fc2.bias"] = n(E, F), zeros(E)
+            sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"] = ones(E), zeros(E)
+        sd[pre + "final_layer_norm.weight"], sd[pre + "final_layer_norm.bias"] = ones(E), zeros(E)
+    return sd
+
+
+def load_local_hf(path: str):
+    """(config dict, state dict) from a local HF directory: safetensors, else a torch file loaded
+    with ``weights_only=True``.  Nothing is fetched from the network."""
+    with open(os.path.join(path, "config.json")) as f:
+        cfg = json.load(f)
+    st = os.path.join(path, "model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        return cfg, load_file(st)
+    pt = os.path.join(path, "pytorch_model.bin")
+    if os.path.exists(pt):
+        return cfg, torch.load(pt, map_location="cpu", weights_only=True)
+    raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
+
+
+class _Layer:
+    __slots__ = ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
+                 "w_qkv_t", "w_o_t", "w_fc1_t", "w_fc2_t")
+
+
+class FrozenCausalLM:
+    """Weights of a frozen GPT-2 / OPT decoder pre-packed for the HIP kernels + forward / dgrad drivers."""
+
+    def __init__(self, cfg: LMConfig, state_dict: Dict[str, Tensor], dtype: torch.dtype = torch.bfloat16, device="cuda"):
+        self.cfg = cfg
+        self.dtype = dtype
+        self.device = torch.device(device)
+        self._pack(state_dict)
+        self._bwd_ready = False
+
+    # ---------------------------------------------------------------- packing
+    def _T(self, t: Tensor) -> Tensor:
+        return t.to(device=self.device, dtype=self.dtype).contiguous()
+
+    def _F(self, t: Tensor) -> Tensor:
+        return t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def _pack(self, sd: Dict[str, Tensor]) -> None:
+        c = self.cfg
+        self.layers = []
+        if c.arch == "gpt2":
+            self.wte = self._T(sd["transformer.wte.weight"])
+            self.wpe = self._T(sd["transformer.wpe.weight"])
+            for i in range(c.n_layer):
+                p = f"transformer.h.{i}."
+                L = _Layer()
+                L.ln1_g, L.ln1_b = self._F(sd[p + "ln_1.weight"]), self._F(sd[p + "ln_1.bias"])
+                # Conv1D stores [in,out]; the forward GEMM wants [out,in] (k contiguous)
+                L.w_qkv, L.b_qkv = self._T(sd[p + "attn.c_attn.weight"].T), self._F(sd[p + "attn.c_attn.bias"])
+                L.w_o, L.b_o = self._T(sd[p + "attn.c_proj.weight"].T), self._F(sd[p + "attn.c_proj.bias"])
+                L.ln2_g, L.ln2_b = self._F(sd[p + "ln_2.weight"]), self._F(sd[p + "ln_2.bias"])
+                L.w_fc1, L.b_fc1 = self._T(sd[p + "mlp.c_fc.weight"].T), self._F(sd[p + "mlp.c_fc.bias"])
+                L.w_fc2, L.b_fc2 = self._T(sd[p + "mlp.c_proj.weight"].T), self._F(sd[p + "mlp.c_proj.bias"])
+                L.w_qkv_t = L.w_o_t = L.w_fc1_t = L.w_fc2_t = None
+                self.layers.append(L)
+            self.lnf_g, self.lnf_b = self._F(sd["transformer.ln_f.weight"]), self._F(sd["transformer.ln_f.bias"])
+            head = sd.get("lm_head.weight")
+        else:
+            pre = "model.decoder."
+            self.wte = self._T(sd[pre + "embed_tokens.weight"])
+            self.wpe = self._T(sd[pre + "embed_positions.weight"])
+            for i in range(c.n_layer):
+                p = f"{pre}layers.{i}."
+                L = _Layer()
+                L.ln1_g, L.ln1_b = self._F(sd[p + "self_attn_layer_norm.weight"]), self._F(sd[p + "self_attn_layer_norm.bias"])
+                L.w_qkv = self._T(torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in "qkv"], dim=0))
+                L.b_qkv = self._F(torch.cat([sd[p + f"self_attn.{n}_proj.bias"] for n in "qkv"], dim=0))
+                L.w_o, L.b_o = self._T(sd[p + "self_attn.out_proj.weight"]), self._F(sd[p + "self_attn.out_proj.bias"])
+                L.ln2_g, L.ln2_b = self._F(sd[p + "final_layer_norm.weight"]), self._F(sd[p + "final_layer_norm.bias"])
+                L.w_fc1, L.b_fc1 = self._T(sd[p + "fc1.weight"]), self._F(sd[p + "fc1.bias"])
+                L.w_fc2, L.b_fc2 = self._T(sd[p + "fc2.weight"]), self._F(sd[p + "fc2.bias"])
+                L.w_qkv_t = L.w_o_t = L.w_fc1_t = L.w_fc2_t = None
+                self.layers.append(L)
+            self.lnf_g, self.lnf_b = self._F(sd[pre + "final_layer_norm.weight"]), self._F(sd[pre + "final_layer_norm.bias"])
+            head = sd.get("lm_head.weight")
+        # lm_head is tied to wte in both families; an untied head is kept separately
+        self.head = self.wte if head is None or head.shape == self.wte.shape and _same(head, self.wte) else self._T(head)
+        self.head_t = None
+
+    @property
+    def vocab(self) -> int:
+        return self.wte.shape[0]
+
+    @property
+    def vpad(self) -> int:
+        return (self.vocab + 7) // 8 * 8
+
+    def _prepare_backward(self) -> None:
+        """Transposed weight copies for the dgrad GEMMs (made once, on the first training step)."""
+        if self._bwd_ready:
+            return
+        for L in self.layers:
+            L.w_qkv_t = L.w_qkv.T.contiguous()
+            L.w_o_t = L.w_o.T.contiguous()
+            L.w_fc1_t = L.w_fc1.T.contiguous()
+            L.w_fc2_t = L.w_fc2.T.contiguous()
+        V, E = self.head.shape
+        self.head_t = torch.zeros((E, self.vpad), device=self.device, dtype=self.dtype)
+        self.head_t[:, :V] = self.head.T
+        self._bwd_ready = True
+
+    def resize_token_embeddings(self, n: int) -> None:
+        """``model.gpt.resize_token_embeddings(len(tokenizer))`` src/trainers/clipcap_exector.py:56.
+        New rows get the mean of the existing embeddings (HF draws them around that mean)."""
+        V, E = self.wte.shape
+        if n == V:
+            return
+        tied = self.head is self.wte
+        new = torch.empty((n, E), device=self.device, dtype=self.dtype)
+        keep = min(n, V)
+        new[:keep] = self.wte[:keep]
+        if n > V:
+            new[V:] = self.wte.float().mean(0).to(self.dtype)
+        self.wte = new
+        if tied:
+            self.head = new
+        else:
+            h = torch.empty((n, E), device=self.device, dtype=self.dtype)
+            h[:keep] = self.head[:keep]
+            if n > V:
+                h[V:] = self.head.float().mean(0).to(self.dtype)
+            self.head = h
+        self.cfg.vocab = n
+        self._bwd_ready = False
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, prefix_rows: Optional[Tensor], src: Tensor, pos: Tensor, mask: Tensor, B: int, S: int, *,
+                labels: Optional[Tensor] = None, save: bool = False, logits: str = "none"):
+        """Run the decoder over ``B`` rows of ``S`` positions.
+
+        ``src/pos/mask``: int32 [B,S] from ``ops.build_prefix_rows`` / ``build_fewshot_rows``;
+        ``prefix_rows``: mapper output rows in the compute dtype.  ``logits``: "none" | "all" | "last".
+        Returns a dict with ``loss``/``count`` (when labels), ``logits`` ([B*S or B, vpad] fp32) and,
+        when ``save``, the tape for :meth:`backward`.
+        """
+        c, T = self.cfg, self.dtype
+        E, H, hd, M = c.n_embd, c.n_head, c.head_dim, B * S
+        scale = hd ** -0.5
+        x = ops.embed_assemble(src, pos, self.wte, prefix_rows, self.wpe)
+        tape = [] if save else None
+        for L in self.layers:
+            if save:
+                a, mean1, rstd1 = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T, save_stats=True)
+            else:
+                a = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T)
+            qkv = ops.gemm(a, L.w_qkv, bias=L.b_qkv)
+            q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+            if save:
+                ctx, lse = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=mask, causal=True, scale=scale, save_lse=True)
+            else:
+                ctx = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=mask, causal=True, scale=scale)
+            x1 = ops.gemm(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True)
+            if save:
+                a2, mean2, rstd2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T, save_stats=True)
+                u = torch.empty((M, c.ffn), device=self.device, dtype=T)
+                f = ops.gemm(a2, L.w_fc1, bias=L.b_fc1, act=c.act, aux_out=u)
+            else:
+                a2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T)
+                f = ops.gemm(a2, L.w_fc1, bias=L.b_fc1, act=c.act)
+            x2 = ops.gemm(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True)
+            if save:
+                tape.append((x, mean1, rstd1, qkv, ctx, lse, x1, mean2, rstd2, u))
+            x = x2
+        out = {}
+        if logits == "last" and labels is None:
+            xl = x.view(B, S, E)[:, -1]                       # strided rows: only the last position is normalised
+            hf = ops.layernorm_fwd(xl, self.lnf_g, self.lnf_b, c.eps, T)
+            out["logits"] = self._head(hf)
+            return out
+        if save:
+            hf, meanf, rstdf = ops.layernorm_fwd(x, self.lnf_g, self.lnf_b, c.eps, T, save_stats=True)
+        else:
+            hf = ops.layernorm_fwd(x, self.lnf_g, self.lnf_b, c.eps, T)
+        out["hidden"] = hf
+        if labels is not None or logits == "all":
+            lg = self._head(hf)
+            out["logits"] = lg
+            if labels is not None:
+                loss, count, row_lse = ops.ce_fwd(lg, labels, self.vocab)
+                out["loss"], out["count"] = loss, count
+                if save:
+                    out["tape"] = dict(layers=tape, x_last=x, meanf=meanf, rstdf=rstdf, logits=lg, labels=labels,
+                                       row_lse=row_lse, count=count, src=src, mask=mask, B=B, S=S)
+        if logits == "last":
+            out["logits_last"] = out["logits"].view(B, S, -1)[:, -1]
+        return out
+
+    def _head(self, hf: Tensor) -> Tensor:
+        """lm_head GEMM into a [rows, vpad] fp32 buffer (pad columns are never read)."""
+        lg = torch.empty((hf.shape[0], self.vpad), device=self.device, dtype=torch.float32)
+        ops.gemm(hf, self.head, out=lg[:, :self.vocab])
+        return lg
+
+    # ---------------------------------------------------------------- backward (dgrad only)
+    def backward(self, tape: dict, gloss: Tensor, n_prefix_rows: int) -> Tensor:
+        """d loss / d prefix_rows.  ``gloss``: float32 [1] upstream gradient of the scalar loss."""
+        self._prepare_backward()
+        c, T = self.cfg, self.dtype
+        E, H, hd = c.n_embd, c.n_head, c.head_dim
+        B, S = tape["B"], tape["S"]
+        M = B * S
+        scale = hd ** -0.5
+        mask = tape["mask"]
+        lowp = T != torch.float32
+
+        def as_T(t):   # fp32 gradient of the residual stream -> GEMM operand dtype
+            return ops.cast_rows(t, T) if lowp else t
+
+        dlog = ops.ce_bwd(tape["logits"], tape["labels"], self.vocab, tape["row_lse"], tape["count"], gloss, T, self.vpad)
+        dhf = ops.gemm(dlog, self.head_t)                                   # [M,E]
+        dx = ops.layernorm_bwd(tape["x_last"], dhf, self.lnf_g, tape["meanf"], tape["rstdf"])
+        for L, (x, mean1, rstd1, qkv, ctx, lse, x1, mean2, rstd2, u) in zip(reversed(self.layers), reversed(tape["layers"])):
+            du = ops.gemm(as_T(dx), L.w_fc2_t, act=c.act, aux_in=u)          # (dx W2) * act'(u)   [M,F]
+            da2 = ops.gemm(du, L.w_fc1_t)                                    # [M,E]
+            dx1 = ops.layernorm_bwd(x1, da2, L.ln2_g, mean2, rstd2, dres=dx, out=dx)
+            dctx = ops.gemm(as_T(dx1), L.w_o_t)                              # [M,E]
+            dqkv = torch.empty_like(qkv)
+            q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+            ops.attention_bwd(q, k, v, ctx, dctx, lse, B, H, S, S, hd, key_mask=mask, causal=True, scale=scale,
+                              dq=dqkv[:, :E], dk=dqkv[:, E:2 * E], dv=dqkv[:, 2 * E:])
+            da = ops.gemm(dqkv, L.w_qkv_t)                                   # [M,E]
+            dx = ops.layernorm_bwd(x, da, L.ln1_g, mean1, rstd1, dres=dx1, out=dx1)
+        return ops.embed_assemble_bwd(tape["src"], dx, n_prefix_rows, T)
+
+
+def _same(a: Tensor, b: Tensor) -> bool:
+    try:
+        return a.data_ptr() == b.data_ptr() or bool(torch.equal(a.to(b.device, b.dtype), b))
+    except Exception:
+        return False

@@ -99,13 +99,13 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], mean: Tensor, 
 
 def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, H: int, Sq: int, Sk: int, hd: int, *,
                   key_mask: Optional[Tensor] = None, causal: bool = False, scale: float = 1.0, save_lse: bool = False,
-                  q_batch_rows: int = 0, kv_batch_rows: int = 0, out: Optional[Tensor] = None):
+                  q_batch_rows: int = 0, kv_batch_rows: int = 0, ld_mask: int = 0, out: Optional[Tensor] = None):
     """``q``: rows [B*Sq, >=H*hd] views (element (b,s,h,d) at row b*Sq+s, col h*hd+d); same for k/v."""
     _dev(q)
     o = out if out is not None else torch.empty((B * Sq, H * hd), device=q.device, dtype=q.dtype)
     lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32) if save_lse else None
     call("eavqa_attention_fwd", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o),
-         q_batch_rows, kv_batch_rows, _p(key_mask), int(causal), float(scale), _p(lse), _stream())
+         q_batch_rows, kv_batch_rows, _p(key_mask), ld_mask, int(causal), float(scale), _p(lse), _stream())
     return (o, lse) if save_lse else o
 
 
@@ -122,7 +122,8 @@ def attention_bwd(q, k, v, o, d_o, lse, B, H, Sq, Sk, hd, *, key_mask=None, caus
     return dq, dk, dv
 
 
-def build_prefix_rows(tokens: Tensor, question_mask: Tensor, L: int, pos_mode: int):
+def build_prefix_rows(tokens: Tensor, question_mask: Tensor, L: int, pos_mode: int, prefix_row_stride: Optional[int] = None,
+                      prefix_row_offset: int = 0):
     """int64 [B,T] tokens/mask -> (src, mask, pos) int32 [B, L+T]."""
     _dev(tokens)
     B, T = tokens.shape
@@ -132,7 +133,8 @@ def build_prefix_rows(tokens: Tensor, question_mask: Tensor, L: int, pos_mode: i
     src = torch.empty((B, S), device=tokens.device, dtype=torch.int32)
     msk = torch.empty_like(src)
     pos = torch.empty_like(src)
-    call("eavqa_build_prefix_rows", B, L, T, _p(tokens), _p(qm), pos_mode, _p(src), _p(msk), _p(pos), _stream())
+    call("eavqa_build_prefix_rows", B, L, T, _p(tokens), _p(qm), pos_mode, L if prefix_row_stride is None else prefix_row_stride,
+         prefix_row_offset, _p(src), _p(msk), _p(pos), _stream())
     return src, msk, pos
 
 
@@ -239,3 +241,14 @@ def cast_rows(x: Tensor, dtype: torch.dtype, out: Optional[Tensor] = None) -> Te
     y = out if out is not None else torch.empty((rows, cols), device=x.device, dtype=dtype)
     call("eavqa_cast_rows", dtype_id(dtype), rows, cols, _p(x), _ld(x), _p(y), _ld(y), _stream())
     return y
+
+
+def copy_rows(src: Tensor, dst: Tensor, B: int, S: int, cols: int, src_batch_rows: int, dst_batch_rows: int, dst_row0: int) -> None:
+    """Strided row copy (KV-cache fill / append); ``src``/``dst`` are 2-D row views."""
+    call("eavqa_copy_rows", dtype_id(src.dtype), B, S, cols, _p(src), _ld(src), src_batch_rows, _p(dst), _ld(dst),
+         dst_batch_rows, dst_row0, _stream())
+
+
+def colsum(x: Tensor, out: Tensor, accumulate: bool) -> None:
+    rows, cols = x.shape
+    call("eavqa_colsum", dtype_id(x.dtype), rows, cols, _p(x), _ld(x), _p(out), int(accumulate), _stream())

@@ -103,7 +103,7 @@ int eavqa_layernorm_bwd(int dtype, int x_f32, int rows, int cols, const void* x,
  * q/k/v/o: `dtype`, element (b, s, h, d) at base[(b*batch_rows + s)*ld + h*hd + d] where
  * batch_rows is q_batch_rows for q/o and kv_batch_rows for k/v (0 = Sq / Sk; a KV cache
  * allocated [B, S_max, E] passes kv_batch_rows = S_max).
- * key_mask: int32 [B,Sk] (0 = padded key) or NULL.  causal: key j visible to query i iff
+ * key_mask: int32, row b at key_mask + b*ld_mask (ld_mask 0 = Sk), 0 = padded key; or NULL.  causal: key j visible to query i iff
  * j <= i + (Sk - Sq).  Masked scores are replaced by -FLT_MAX (HF adds finfo.min), so a
  * fully masked row yields the uniform average over all Sk keys, never NaN.
  * lse: float32 [B,H,Sq] log-sum-exp of the scaled masked scores (NULL in inference).
@@ -113,7 +113,7 @@ int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,
                         const void* q, int64_t ldq, const void* k, int64_t ldk,
                         const void* v, int64_t ldv, void* o, int64_t ldo,
                         int64_t q_batch_rows, int64_t kv_batch_rows,
-                        const int32_t* key_mask, int causal, float scale, float* lse, void* stream);
+                        const int32_t* key_mask, int64_t ld_mask, int causal, float scale, float* lse, void* stream);
 /* Backward (dense batches only: batch_rows = Sq / Sk): dq/dk/dv in `dtype`, addressed as q/k/v
  * with leading dims lddq/lddk/lddv.
  * delta: float32 scratch [B,H,Sq] (rowsum(do*o), written by the call). */
@@ -129,12 +129,15 @@ int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int hd,
  * Integer / index work is bit-exact against the oracle.
  */
 /* ClipCaptionModel.forward/generate clipcap.py:303-321,353-381: row b of the LM input is
- * [L prefix slots | T text tokens].  Writes src[b,s] = -(1 + b*L + s) for s < L (prefix row of
- * image b), else token id; mask_out[b,s] = 1 for s < L else question_mask; pos[b,s] = s
+ * [L prefix slots | T text tokens].  Writes src[b,s] = -(1 + b*prefix_row_stride + prefix_row_offset + s)
+ * for s < L (row of the mapper output buffer holding prefix slot s of sample b; stride L, offset 0 for
+ * the MLP mapper, stride clip_length+L, offset clip_length for the transformer mapper's residual
+ * stream clipcap.py:220), else token id; mask_out[b,s] = 1 for s < L else question_mask; pos[b,s] = s
  * (pos_mode 0, GPT-2 HF:gpt2 :571-574) or cumsum(mask)*mask - 1 + 2 (pos_mode 1, OPT HF:opt :45-70).
  * tokens/question_mask int64 [B,T] (the reference hands over int64); outputs int32 [B,L+T]. */
 int eavqa_build_prefix_rows(int B, int L, int T, const int64_t* tokens, const int64_t* question_mask,
-                            int pos_mode, int32_t* src, int32_t* mask_out, int32_t* pos, void* stream);
+                            int pos_mode, int prefix_row_stride, int prefix_row_offset,
+                            int32_t* src, int32_t* mask_out, int32_t* pos, void* stream);
 /* VCT0Model.insert_prefix_into_input src/models/vct0.py:494-533 (golden vectors
  * src/models/vct0_test.py:79-211): the n-th sentinel token of row b (ids special_token_id - i,
  * i = 0..n_img-1) expands into the L prefix slots of image n.  T_out = T + (L-1)*n_img.
@@ -143,6 +146,14 @@ int eavqa_build_prefix_rows(int B, int L, int T, const int64_t* tokens, const in
 int eavqa_build_fewshot_rows(int B, int T, int L, int n_img, int64_t special_token_id,
                              const int64_t* tokens, const int64_t* question_mask, int pos_mode,
                              int32_t* src, int32_t* mask_out, int32_t* pos, int32_t* status, void* stream);
+/* dst[(b*dst_batch_rows + dst_row0 + s)*ldd + c] = src[(b*src_batch_rows + s)*lds + c], b < B, s < S,
+ * c < cols (`dtype` -> `dtype`): fills / appends the per-layer KV cache [B, S_max, E] from the QKV
+ * projection rows (the reference re-runs the whole sequence instead, clipcap.py:414-419). cols % 4 == 0. */
+int eavqa_copy_rows(int dtype, int B, int S, int cols, const void* src, int64_t lds, int64_t src_batch_rows,
+                    void* dst, int64_t ldd, int64_t dst_batch_rows, int64_t dst_row0, void* stream);
+/* out[c] (+)= sum_r x[r, c]  (float32 out; `dtype` in): bias gradients of the mapper's Linear layers and
+ * the gradient of TransformerMapper.prefix_const (clipcap.py:235-237).  accumulate != 0 adds to out. */
+int eavqa_colsum(int dtype, int rows, int cols, const void* x, int64_t ldx, float* out, int accumulate, void* stream);
 /* x[b,s,:] = (src >= 0 ? wte[src] : prefix_rows[-src-1]) + wpe[pos]   (float32 out, residual stream)
  * wte/wpe/prefix_rows in `dtype`; wpe may be NULL.  Also the append path of
  * _generate_from_embeddings clipcap.py:423,440-442.  E % 4 == 0. */
