@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: mapper training samples/s on Conceptual-Captions-shaped
+synthetic batches (BASELINE.json metric M1), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one per-GPU batch: CLIP ViT encode -> mapping network ->
+frozen causal LM over [prefix | caption] -> shifted CE -> backward into the mapper -> gradient
+all-reduce (RCCL, N > 1) -> fused AdamW.  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line (contract in the task description) that also carries
+  roofline     - achieved TFLOP/s of the dominant kernel (the MFMA GEMM) from HIP events recorded on
+                 the launch stream around every GEMM launch of an extra, instrumented step that
+                 runs right after the timed region (so the timed value is not perturbed), and
+  cpu_baseline - the CPU oracle (oracle/ref_cpu.py, kind "port") timed on this host's cores on a
+                 bounded sample of the same workload (N = 1, rank 0 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: the configuration the metric is quoted on
+    "cfg2": dict(vit="ViT-B/32", lm="gpt2-large", mapping_type="mlp", prefix_length=10, batch=64, text_len=32,
+                 desc="CLIP ViT-B/32 -> GPT-2-large (774M), MLP mapper, prefix 10, CC-shaped synthetic batches"),
+    "cfg1": dict(vit="ViT-B/32", lm="gpt2", mapping_type="mlp", prefix_length=10, batch=4, text_len=32,
+                 desc="CLIP ViT-B/32 -> GPT-2-small, MLP mapper, batch 4 (the reference's CPU-runnable case)"),
+    "cfg3": dict(vit="ViT-L/14", lm="facebook/opt-1.3b", mapping_type="mlp", prefix_length=10, batch=64, text_len=32,
+                 desc="CLIP ViT-L/14 -> OPT-1.3B, MLP mapper, prefix 10"),
+}
+
+# algorithmic FLOPs per sample: ViT fwd + 3 x mapper + 2 x LM fwd, 2*params*tokens for
+# GEMMs + 4*S^2*E per layer for attention
+def flops_per_sample(vit_cfg, lm_cfg, L, S, D):
+    W, N = vit_cfg.width, vit_cfg.n_patch + 1
+    vit = vit_cfg.n_layer * (2 * N * (4 * W * W + 2 * W * vit_cfg.mlp) + 4 * N * N * W) + 2 * vit_cfg.n_patch * 3 * vit_cfg.patch ** 2 * W + 2 * W * vit_cfg.proj
+    E, F, V = lm_cfg.n_embd, lm_cfg.ffn, lm_cfg.vocab
+    lm = lm_cfg.n_layer * (2 * S * (4 * E * E + 2 * E * F) + 4 * S * S * E) + 2 * S * E * V
+    H = E * L // 2
+    mapper = 2 * (D * H + H * E * L)
+    return vit + 3 * mapper + 2 * lm
+
+
+def build_workload(name, dtype, device, rank):
+    from eavqa_amd.data.synthetic import cc_batch
+    from eavqa_amd.models.clip_vit import KNOWN_VITS, ClipVisionEncoder, random_init_vit_state_dict
+    from eavqa_amd.models.clipcap import ClipCaptionPrefix
+    from eavqa_amd.models.lm import KNOWN_CONFIGS, FrozenCausalLM, LMConfig, random_init_state_dict
+    from eavqa_amd.trainers.optim import FusedAdamW
+
+    w = WORKLOADS[name]
+    vcfg = KNOWN_VITS[w["vit"]]
+    lcfg = LMConfig.from_hf_dict(KNOWN_CONFIGS[w["lm"]])
+    vit = ClipVisionEncoder(vcfg, random_init_vit_state_dict(vcfg, 2021, device), dtype, device)
+    lm = FrozenCausalLM(lcfg, random_init_state_dict(lcfg, 2021, device), dtype, device)
+    torch.manual_seed(2021)   # mapper init = nn.Linear default under the reference seed
+    model = ClipCaptionPrefix(prefix_length=w["prefix_length"], prefix_size=vcfg.proj, mapping_type=w["mapping_type"],
+                              lm=lm, dtype=dtype, device=device).train()
+    opt = FusedAdamW(model.clip_project.flat, lr=1e-4)
+    pad = lcfg.eos_token_id
+    batch = cc_batch(w["batch"], lcfg.vocab, pad, image_size=vcfg.image, max_len=w["text_len"], seed=2021 + rank, device=device)
+    return w, vcfg, lcfg, vit, model, opt, batch, pad
+
+
+class Stepper:
+    """One training step; with N > 1 the all-reduce of step i overlaps the ViT encode of step i+1 and AdamW(i)
+    runs after it (the mapper gradient is the last thing backward produces, so there is nothing else to hide behind)."""
+
+    def __init__(self, vit, model, opt, batch, pad, sync):
+        self.vit, self.model, self.opt, self.batch, self.pad, self.sync = vit, model, opt, batch, pad, sync
+        self.pending_update = False
+
+    def _apply_update(self):
+        if self.pending_update:
+            self.sync.finish()
+            self.opt.step(grad_scale=self.sync.grad_scale)
+            self.opt.zero_grad()
+            self.pending_update = False
+
+    def step(self):
+        b = self.batch
+        emb = self.vit.encode_image(b["pixel_values"])          # independent of the mapper: overlaps the exchange
+        self._apply_update()                                     # AdamW of the previous step
+        out = self.model(question_tokens=b["input_ids"], prefix=emb, question_mask=b["attention_mask"], labels=b["labels"],
+                         pad_token_id=self.pad)
+        out.loss.backward()
+        self.sync.start()
+        self.pending_update = True
+        return out.loss
+
+    def flush(self):
+        self._apply_update()
+
+
+def cpu_baseline(name, n_samples, threads):
+    """The oracle (CPU restatement, fp32) on a bounded sample of the same workload: one training step
+    (ViT encode, mapper, LM forward, backward into the mapper, AdamW) over ``n_samples`` samples."""
+    import oracle
+    from eavqa_amd.data.synthetic import cc_batch
+    from eavqa_amd.models.clip_vit import KNOWN_VITS, random_init_vit_state_dict
+    from eavqa_amd.models.lm import KNOWN_CONFIGS, LMConfig, random_init_state_dict
+
+    torch.set_num_threads(threads)
+    w = WORKLOADS[name]
+    vcfg, lcfg = KNOWN_VITS[w["vit"]], LMConfig.from_hf_dict(KNOWN_CONFIGS[w["lm"]])
+    vsd = random_init_vit_state_dict(vcfg, 2021, "cpu")
+    lsd = random_init_state_dict(lcfg, 2021, "cpu")
+    L, E, D = w["prefix_length"], lcfg.n_embd, vcfg.proj
+    torch.manual_seed(2021)
+    l0, l2 = torch.nn.Linear(D, E * L // 2), torch.nn.Linear(E * L // 2, E * L)
+    mapper = {"model.0.weight": l0.weight.detach().requires_grad_(True), "model.0.bias": l0.bias.detach().requires_grad_(True),
+              "model.2.weight": l2.weight.detach().requires_grad_(True), "model.2.bias": l2.bias.detach().requires_grad_(True)}
+    b = cc_batch(n_samples, lcfg.vocab, lcfg.eos_token_id, image_size=vcfg.image, max_len=w["text_len"], seed=2021, device="cpu")
+    ocfg = dict(arch=lcfg.arch, n_layer=lcfg.n_layer, n_head=lcfg.n_head, act=lcfg.act)
+    vc = dict(width=vcfg.width, n_layer=vcfg.n_layer, n_head=vcfg.n_head, patch=vcfg.patch)
+    state = {k: (torch.zeros_like(v), torch.zeros_like(v)) for k, v in mapper.items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        emb = oracle.clip_vit_encode(vsd, vc, b["pixel_values"])
+    loss, _ = oracle.clipcap_forward(lsd, ocfg, mapper, dict(prefix_length=L, mapping_type="mlp"), b["input_ids"], emb,
+                                     b["attention_mask"], b["labels"])
+    loss.backward()
+    with torch.no_grad():
+        for k, p in mapper.items():
+            oracle.adamw_step(p, p.grad, state[k][0], state[k][1], 1, 1e-4)
+    dt = time.perf_counter() - t0
+    return dict(value=round(n_samples / dt, 3), unit="samples/s", cores=threads, kind="port",
+                sample=f"1 training step of {n_samples} samples of the same workload (oracle/ref_cpu.py, fp32, {dt:.1f} s)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--cpu-baseline-samples", type=int, default=8, help="0 disables the CPU baseline leg")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from eavqa_amd import _lib, ops
+    from eavqa_amd.trainers.data_parallel import GradSync, init_from_env
+
+    rank, local, world = init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP extension is the only compute path")
+    torch.cuda.set_device(local)
+    device = f"cuda:{local}"
+    if _lib.load().eavqa_check_device() != 0:
+        raise SystemExit("device is not gfx950")
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    w, vcfg, lcfg, vit, model, opt, batch, pad = build_workload(args.workload, dtype, device, rank)
+    sync = GradSync(model.clip_project.flat.grad, world)
+    stepper = Stepper(vit, model, opt, batch, pad, sync)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        stepper.step()
+    stepper.flush()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = stepper.step()
+    stepper.flush()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    B, S = w["batch"], w["prefix_length"] + batch["input_ids"].shape[1]
+    value = world * B * args.steps / dt
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        roof = gemm_roofline(stepper, ops)
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_baseline_samples > 0:
+        cpu = cpu_baseline(args.workload, args.cpu_baseline_samples, os.cpu_count() or 1)
+
+    if rank == 0:
+        fps = flops_per_sample(vcfg, lcfg, w["prefix_length"], S, vcfg.proj)
+        line = {
+            "metric": "mapper_train_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {w['desc']}; per-GPU batch {B}, S={S}; fwd+bwd+AdamW; random-init weights",
+                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
+                       "algorithmic_gflop_per_sample": round(fps / 1e9, 1),
+                       "step_tflops": round(value * fps / 1e12, 1), "final_loss": round(float(loss.item()), 4)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def gemm_roofline(stepper, ops):
+    """HIP events (torch.cuda.Event records on the current stream = the stream eavqa_gemm launches on) around every
+    GEMM launch of one extra step: achieved = algorithmic FLOPs per launch / average launch duration."""
+    real = ops.gemm
+    recs = []
+
+    def timed(a, b, *, a_kc=True, b_kc=True, **kw):
+        M, K = a.shape if a_kc else (a.shape[1], a.shape[0])
+        N = b.shape[0] if b_kc else b.shape[1]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = real(a, b, a_kc=a_kc, b_kc=b_kc, **kw)
+        e1.record()
+        recs.append((2.0 * M * N * K, e0, e1))
+        return out
+
+    ops.gemm = timed
+    try:
+        stepper.step()
+        stepper.flush()
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = real
+    flops = sum(r[0] for r in recs)
+    secs = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
+    n = len(recs)
+    achieved = flops / secs / 1e12
+    peak = 2500.0 if stepper.model.dtype == torch.bfloat16 else 157.3
+    return {"bound": "mfma", "kernel": "gemm_bf16_kernel" if stepper.model.dtype == torch.bfloat16 else "gemm_f32_kernel",
+            "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "launches_per_step": n, "gflop_per_launch": round(flops / n / 1e9, 2), "avg_launch_us": round(secs / n * 1e6, 2),
+            "gemm_ms_per_step": round(secs * 1e3, 3)}
+
+
+if __name__ == "__main__":
+    main()

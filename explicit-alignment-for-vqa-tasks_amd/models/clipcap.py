@@ -444,6 +444,42 @@ class ClipCaptionModel(nn.Module):
         return greedy_decode(lm, rows, src, mask, pos, B, L + T, max_length, pad_token_id, eos_token_id, use_cache)
 
 
+    @torch.no_grad()
+    def generate_fewshot(self, question_tokens: Tensor, prefix: Tensor, question_mask: Optional[Tensor] = None,
+                         num_shots: Optional[int] = None, special_token_id: int = 32099, max_length: Optional[int] = 10,
+                         pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None,
+                         use_cache: bool = True) -> List[List[int]]:
+        """Few-shot prompt path: the causal-LM counterpart of ``VCT0Model.generate`` with
+        ``insert_prefix_into_input`` (src/models/vct0.py:446-464,494-533).  ``prefix``: [B, n_img, D] (or
+        [B, n_img, 1, D]) CLIP embeddings; the n-th sentinel token (ids ``special_token_id - i``) of each row
+        expands into the L prefix vectors of image n."""
+        from .decode import greedy_decode
+        if self.mapping_type != "mlp":
+            raise NotImplementedError("several images per row need the MLP mapper (as in the reference configs)")
+        dev = self.device_
+        lm = self.gpt
+        tok = question_tokens.to(dev)
+        qm = question_mask.to(dev) if question_mask is not None else torch.ones_like(tok)
+        B, T = tok.shape
+        prefix = prefix.to(dev).reshape(B, -1, prefix.shape[-1])
+        n_img = prefix.shape[1]
+        if num_shots is not None and num_shots + 1 != n_img:
+            raise ValueError("num_shots + 1 must equal the number of images per row")
+        pad_token_id = pad_token_id if pad_token_id is not None else lm.cfg.pad_token_id
+        eos_token_id = eos_token_id if eos_token_id is not None else lm.cfg.eos_token_id
+        if eos_token_id is not None and pad_token_id is None:
+            raise ValueError("If `eos_token_id` is defined, make sure that `pad_token_id` is defined.")
+        L = self.prefix_length
+        rows = self.clip_project(prefix).reshape(-1, self.gpt_embedding_size)          # [(b, n, l), E]
+        tok_ext = torch.cat([tok, torch.zeros((B, max_length), dtype=tok.dtype, device=dev)], dim=1)
+        qm_ext = torch.cat([qm.to(torch.int64), torch.ones((B, max_length), dtype=torch.int64, device=dev)], dim=1)
+        src, mask, pos, status = ops.build_fewshot_rows(tok_ext, qm_ext, L, n_img, special_token_id, lm.cfg.pos_mode)
+        if not bool((status == n_img).all().item()):
+            raise ValueError("every row must hold exactly one sentinel token per image")   # vct0.py:512 .view fails
+        S0 = T + (L - 1) * n_img
+        return greedy_decode(lm, rows, src, mask, pos, B, S0, max_length, pad_token_id, eos_token_id, use_cache)
+
+
 class ClipCaptionPrefix(ClipCaptionModel):
     """``ClipCaptionPrefix`` clipcap.py:590-599: only the mapper trains; the LM stays frozen / eval."""
 

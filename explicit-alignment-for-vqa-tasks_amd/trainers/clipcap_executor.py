@@ -1,0 +1,171 @@
+"""``ClipCapExecutor``: the reference's Lightning executor surface (src/trainers/clipcap_exector.py)
+over the HIP model classes.
+
+Kept from the reference: construction from ``config.model_config.{ModelClass, model_args}`` by name
+lookup (:52-53), ``tokenizer.pad_token = eos_token`` + ``resize_token_embeddings`` (:55-56),
+``configure_optimizers`` (AdamW defaults + constant-with-warmup schedule, :58-130),
+``training_step(sample_batched, batch_idx)`` -> ``{"loss": ...}`` with the reference's label
+construction (:134-150) and ``train/loss`` / ``train/lr[i]`` logging (:176-190), and
+``_generative_step`` -> ``model.generate`` + decode (:213-311).
+
+``pytorch_lightning`` is not available offline, so the executor is a plain class whose methods
+have Lightning's names and signatures; ``fit`` below is the minimal loop (accumulate_grad_batches as
+src/main.py:118 passes it to the Trainer, data-parallel gradient exchange over RCCL).
+In addition to the reference's pre-extracted ``clip_embeddings`` a batch may carry raw
+``pixel_values``: then the CLIP ViT runs in the loop (the north-star path).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Iterable, Optional
+
+import torch
+
+from .. import ops
+from ..models.clipcap import ClipCaptionModel, ClipCaptionPrefix  # noqa: F401  (looked up by name, :52)
+from ..utils.attrdict import AttrDict
+from .data_parallel import GradSync
+from .optim import ConstantScheduleWithWarmup, FusedAdamW
+
+
+class ClipCapExecutor:
+    def __init__(self, config, data_loader=None, *, vision_encoder=None, model=None, dtype=torch.bfloat16, device="cuda"):
+        self.config = config
+        self.data_loader = data_loader
+        self.device = torch.device(device)
+        self.tokenizer = getattr(data_loader, "tokenizer", None)
+        self.decoder_tokenizer = getattr(data_loader, "decoder_tokenizer", self.tokenizer)
+        if model is None:
+            ModelClass = globals()[self.config.model_config.ModelClass]                     # :52
+            model = ModelClass(**dict(self.config.model_config.model_args), dtype=dtype, device=device)   # :53
+        self.model = model
+        self.vision_encoder = vision_encoder
+        if self.tokenizer is not None:
+            if getattr(self.tokenizer, "pad_token_id", None) is None:
+                self.tokenizer.pad_token = self.tokenizer.eos_token                         # :55
+            self.model.gpt.resize_token_embeddings(len(self.tokenizer))                     # :56
+        self.global_step = 0
+        self.logged: Dict[str, Any] = {}
+        self.optimizer = None
+        self.scheduler = None
+        self.grad_sync: Optional[GradSync] = None
+
+    # ------------------------------------------------------------------ Lightning-named hooks
+    def log(self, name, value, **kwargs):
+        self.logged[name] = value
+
+    def configure_optimizers(self):
+        """clipcap_exector.py:58-130 ("linear"/"cosine" schedules are not on the benchmarked path)."""
+        tr = self.config.train
+        self.optimizer = FusedAdamW(self.model.clip_project.flat, lr=tr.lr)
+        sched = tr.get("scheduler", "none")
+        if sched not in ("none", None, "constant"):
+            raise NotImplementedError(f"scheduler {sched!r}: only the reference default (constant with warmup) is built")
+        warm = tr.get("additional", {}).get("warmup_steps", 0)
+        self.scheduler = ConstantScheduleWithWarmup(self.optimizer, warm)
+        return {"optimizer": self.optimizer, "lr_scheduler": {"scheduler": self.scheduler, "interval": "step", "frequency": 1}}
+
+    def _clip_embeddings(self, batch) -> torch.Tensor:
+        if "clip_embeddings" in batch:
+            return batch["clip_embeddings"].to(self.device)                                 # :158-160
+        if self.vision_encoder is None:
+            raise KeyError("batch has no clip_embeddings and no vision encoder was given")
+        px = batch["pixel_values"].to(self.device)
+        if px.dim() == 5:                                                                   # [B, n_img, 3, H, W]
+            B, n = px.shape[:2]
+            return self.vision_encoder.encode_image(px.reshape(B * n, *px.shape[2:])).view(B, n, -1)
+        return self.vision_encoder.encode_image(px)
+
+    def training_step(self, sample_batched, batch_idx):
+        """clipcap_exector.py:132-195.  VQA batches (``input_ids`` with a <BOS>-separated answer) get the
+        reference's label masking; CC batches arrive with ``labels`` already masked by the collate."""
+        ids = sample_batched["input_ids"].to(self.device)
+        mask = sample_batched["attention_mask"].to(self.device)
+        pad_id = self._pad_id()
+        if "labels" in sample_batched and self.config.get("data_loader", {}).get("type", "") == "DataLoaderConceptualCaptions":
+            labels = sample_batched["labels"].to(self.device)
+        else:
+            bos = getattr(self.tokenizer, "bos_token_id", None)
+            labels = ops.build_labels(ids, 0, pad_id, -1 if bos is None else bos, mode=0)   # :134-150
+        prefix = self._clip_embeddings(sample_batched)
+        out = self.model(question_tokens=ids, labels=labels, prefix=prefix, question_mask=mask, pad_token_id=pad_id)   # :165-171
+        loss = out.loss
+        for i, lr in enumerate(self.scheduler.get_last_lr() if self.scheduler else []):
+            self.log(f"train/lr[{i}]", lr, prog_bar=True, on_step=True, logger=True)
+        self.log("train/loss", loss, on_step=True, on_epoch=True, logger=True)
+        return {"loss": loss}
+
+    def _pad_id(self) -> int:
+        if self.tokenizer is not None and getattr(self.tokenizer, "pad_token_id", None) is not None:
+            return self.tokenizer.pad_token_id
+        cfg = self.model.gpt.cfg
+        return cfg.pad_token_id if cfg.pad_token_id is not None else cfg.eos_token_id
+
+    def validation_step(self, sample_batched, batch_idx):
+        return self._generative_step(sample_batched, batch_idx)
+
+    def test_step(self, sample_batched, batch_idx):
+        return self._generative_step(sample_batched, batch_idx)
+
+    def _generative_step(self, sample_batched, batch_idx):
+        """clipcap_exector.py:213-311 (the wandb table / vqa lookup bookkeeping stays with the caller)."""
+        ids = sample_batched["generative_input_ids"].to(self.device)
+        mask = sample_batched["generative_attention_mask"].to(self.device)
+        prefix = self._clip_embeddings(sample_batched)
+        max_length = self.config.data_loader.additional.max_target_length
+        eos = getattr(self.tokenizer, "eos_token_id", self.model.gpt.cfg.eos_token_id)
+        outputs = self.model.generate(question_tokens=ids, question_mask=mask, prefix=prefix, max_length=max_length,
+                                      pad_token_id=self._pad_id(), eos_token_id=eos)        # :236-243
+        predictions = []
+        bos = getattr(self.decoder_tokenizer, "bos_token_id", None)
+        for index, output_sequence in enumerate(outputs):
+            if bos is not None and bos in output_sequence:
+                output_sequence = output_sequence[output_sequence.index(bos):]              # :261-264
+            decoded = (self.decoder_tokenizer.decode(output_sequence, skip_special_tokens=True)
+                       if self.decoder_tokenizer is not None else output_sequence)
+            qid = sample_batched["question_ids"][index] if "question_ids" in sample_batched else index
+            predictions.append({"question_id": qid, "answer": decoded})
+        return {"predictions": predictions, "outputs": outputs,
+                "question_ids": sample_batched.get("question_ids"), "answers": sample_batched.get("answers")}
+
+    # ------------------------------------------------------------------ minimal trainer loop
+    def fit(self, batches: Iterable[dict], accumulate_grad_batches: int = 1, max_steps: Optional[int] = None):
+        """What ``trainer.fit(executor)`` does for this path (src/main.py:184-187): forward, backward into the
+        mapper, every ``accumulate_grad_batches``-th batch average gradients across ranks and apply AdamW."""
+        if self.optimizer is None:
+            self.configure_optimizers()
+        if self.grad_sync is None:
+            self.grad_sync = GradSync(self.model.clip_project.flat.grad)
+        self.model.train()
+        losses = []
+        for batch_idx, batch in enumerate(batches):
+            if max_steps is not None and self.global_step >= max_steps:
+                break
+            loss = self.training_step(batch, batch_idx)["loss"]
+            loss.backward()
+            losses.append(loss.detach())
+            if (batch_idx + 1) % accumulate_grad_batches == 0:
+                self.grad_sync.start()
+                self.grad_sync.finish()
+                self.optimizer.step(grad_scale=self.grad_sync.grad_scale / accumulate_grad_batches)
+                self.optimizer.zero_grad()
+                self.scheduler.step()
+                self.global_step += 1
+        return losses
+
+    # ------------------------------------------------------------------ checkpoints (mapper only + LM identity)
+    def state_dict(self):
+        sd = {"model.clip_project." + k: v.detach().cpu() for k, v in self.model.clip_project.state_dict().items()}
+        return {"state_dict": sd, "global_step": self.global_step,
+                "optimizer": None if self.optimizer is None else {k: (v.cpu() if torch.is_tensor(v) else v)
+                                                                  for k, v in self.optimizer.state_dict().items()}}
+
+    def load_state_dict(self, ckpt) -> None:
+        """Accepts this build's checkpoints and a Lightning ``.ckpt`` state_dict of the reference, whose keys are
+        prefixed ``model.`` and include the whole frozen LM (``model.gpt.*`` entries are ignored: the LM is
+        identified by ``model_args.model_version``)."""
+        sd = ckpt.get("state_dict", ckpt)
+        mapper = {k[len("model.clip_project."):]: v for k, v in sd.items() if k.startswith("model.clip_project.")}
+        self.model.clip_project.load_state_dict(mapper, strict=True)
+        self.global_step = int(ckpt.get("global_step", 0))
+        if ckpt.get("optimizer") and self.optimizer is not None:
+            self.optimizer.load_state_dict({k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in ckpt["optimizer"].items()})

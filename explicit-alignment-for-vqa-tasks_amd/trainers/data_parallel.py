@@ -1,0 +1,70 @@
+"""Data-parallel gradient exchange for mapper training: one process per GPU, RCCL over xGMI.
+
+Samples are independent and both the ViT and the LM are frozen replicas, so the only exchange is
+the mapper gradient - ONE flat float32 buffer, averaged across ranks (Lightning-DDP
+semantics: per-rank mean loss, gradients averaged).  The collective runs on its own stream; the
+caller overlaps it with the next batch's ViT encode, which does not depend on the mapper, and
+applies AdamW afterwards (mapper gradients arrive last in backward, so there is nothing else to
+hide behind).  The division by world size is folded into the fused AdamW (``grad_scale``).
+
+``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """(rank, local_rank, world) from torchrun's environment; initialises the process group when world > 1."""
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        backend = backend or os.environ.get("EAVQA_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class GradSync:
+    """Sum-all-reduce of a flat gradient buffer on a side stream (no-op for a single rank)."""
+
+    def __init__(self, flat_grad: torch.Tensor, world: Optional[int] = None, group=None):
+        self.buf = flat_grad
+        self.group = group
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.on_gpu = flat_grad.is_cuda
+        self.stream = torch.cuda.Stream() if (self.on_gpu and self.world > 1) else None
+        self._pending = None
+
+    @property
+    def grad_scale(self) -> float:
+        """Factor that turns the summed gradient into the cross-rank mean."""
+        return 1.0 / self.world
+
+    def start(self) -> None:
+        """Enqueue the all-reduce after everything already queued on the current stream."""
+        if self.world == 1:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._pending = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._pending = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self) -> None:
+        """Make the current stream wait for the exchange (call right before the optimiser step)."""
+        if self.world == 1 or self._pending is None:
+            return
+        self._pending.wait()
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self._pending = None
