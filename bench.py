@@ -138,6 +138,20 @@ def cpu_baseline(name, n_samples, threads):
                 sample=f"1 training step of {n_samples} samples of the same workload (oracle/ref_cpu.py, fp32, {dt:.1f} s)")
 
 
+def log(msg):
+    """Progress on stderr (stdout carries only the JSON line)."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads() -> int:
+    """CPU threads this process may really use: the affinity mask, capped at the GPU box's 16-core share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, int(os.environ.get("EAVQA_CPU_THREADS", "16"))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,7 +177,10 @@ def main():
         raise SystemExit("device is not gfx950")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
+    log(f"building workload {args.workload} ({args.dtype}) on {device}")
     w, vcfg, lcfg, vit, model, opt, batch, pad = build_workload(args.workload, dtype, device, rank)
+    torch.cuda.synchronize()
+    log("workload built")
     sync = GradSync(model.clip_project.flat.grad, world)
     stepper = Stepper(vit, model, opt, batch, pad, sync)
 
@@ -174,16 +191,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         stepper.step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     stepper.flush()
     barrier()
+    log("warmup done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = stepper.step()
     stepper.flush()
     barrier()
     dt = time.perf_counter() - t0
+    log(f"timed region: {args.steps} steps in {dt:.3f} s")
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -195,9 +217,12 @@ def main():
     roof = None
     if not args.no_roofline and rank == 0:
         roof = gemm_roofline(stepper, ops)
+        log(f"roofline pass done: {roof}")
     cpu = None
     if rank == 0 and world == 1 and args.cpu_baseline_samples > 0:
-        cpu = cpu_baseline(args.workload, args.cpu_baseline_samples, os.cpu_count() or 1)
+        log(f"cpu baseline on {host_threads()} threads ...")
+        cpu = cpu_baseline(args.workload, args.cpu_baseline_samples, host_threads())
+        log(f"cpu baseline done: {cpu}")
 
     if rank == 0:
         fps = flops_per_sample(vcfg, lcfg, w["prefix_length"], S, vcfg.proj)

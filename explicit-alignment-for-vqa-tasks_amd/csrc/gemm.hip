@@ -245,6 +245,151 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     epilogue<bf16_t>(p, Cs, m0, n0);
 }
 
+
+// ===================================================== bf16 fast path ===
+// Both operands k-contiguous and K % 32 == 0 (every GEMM of the frozen ViT / LM, forward and dgrad,
+// after weight pre-packing).  Differences from the general kernel above:
+//   * global -> LDS by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write;
+//   * BK = 32, a ring of 4 LDS stages (16 KiB each: A 8 KiB + B 8 KiB), tiles t+1..t+3 in flight
+//     while tile t is multiplied; ONE raw s_barrier per K-tile with a counted vmcnt (never 0 in
+//     the steady state), so the DMA stays in flight across barriers;
+//   * 64-byte LDS rows with the 16-byte chunk XOR-swizzled by (-(row >> 2)) & 3: the 16 lanes of
+//     every ds_read_b128 lane group land on 16 different 16-byte slots of the 256-byte bank row.
+//     LDS-DMA writes linearly (wave base + lane * 16), so the swizzle is applied to the per-lane
+//     SOURCE address and again on the fragment read (same involution);
+//   * rows beyond M / N are clamped to the last valid row (their products only reach output rows
+//     that are never stored), so no lane is predicated off and the DMA count per wave is exact;
+//   * the LDS footprint (ring 64 KiB, C staging 66 KiB) lets two workgroups share a CU;
+//   * block -> tile map: each XCD (blockIdx % 8) owns a rectangle of the tile grid so that the
+//     A / B panels it re-reads stay in its own 4 MiB L2.
+constexpr int FBK = 32, FSTAGES = 4;
+constexpr int FOPER = 128 * FBK * 2;        // 8 KiB per operand per stage
+constexpr int FSTAGE = 2 * FOPER;           // 16 KiB
+
+__device__ __forceinline__ int fswz(int row, int kc) { return row * 64 + ((kc ^ ((-(row >> 2)) & 3)) << 4); }
+
+struct FastMap { int gx, gy; };
+
+__device__ __forceinline__ bool fast_tile(const GemmParams& p, int gx, int gy, int& tm, int& tn) {
+    const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int xi = xcd % gx, yi = xcd / gx;
+    const int qm = p.tiles_m / gx, rm = p.tiles_m % gx, qn = p.tiles_n / gy, rn = p.tiles_n % gy;
+    const int m_begin = xi * qm + min(xi, rm), m_cnt = qm + (xi < rm ? 1 : 0);
+    const int n_begin = yi * qn + min(yi, rn), n_cnt = qn + (yi < rn ? 1 : 0);
+    if (m_cnt == 0 || local >= m_cnt * n_cnt) return false;
+    tm = m_begin + local % m_cnt;
+    tn = n_begin + local / m_cnt;
+    return true;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, int gx, int gy) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tm, tn;
+    if (!fast_tile(p, gx, gy, tm, tn)) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+
+    // per-lane DMA sources: chunk c = wave*64 + lane + 256*i of the [128 rows][4 chunks] image
+    const bf16_t* asrc[2];
+    const bf16_t* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c >> 2, pc = c & 3;
+        const int kc = pc ^ ((-(row >> 2)) & 3);
+        asrc[i] = A + (int64_t)min(m0 + row, p.M - 1) * p.lda + kc * 8;
+        bsrc[i] = B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + kc * 8;
+    }
+    const int dma_off = wave * 1024;     // wave-uniform LDS offset of this wave's 64 chunks
+
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & (FSTAGES - 1)) * FSTAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * FBK),
+                                             (__attribute__((address_space(3))) void*)(st + dma_off + i * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * FBK),
+                                             (__attribute__((address_space(3))) void*)(st + FOPER + dma_off + i * 4096), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / FBK;
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+
+    const int frow = lane & 15, fk = lane >> 4;
+    const int a_off = fswz(wm * 64 + frow, fk);          // + i * 16 rows * 64 B
+    const int b_off = FOPER + fswz(wn * 64 + frow, fk);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = nk - 1 - kt;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 3 < nk) issue(kt + 3);
+        const char* st = smem + (kt & (FSTAGES - 1)) * FSTAGE;
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();   // every wave is done with the ring before it becomes the C staging tile
+
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                const int col = wn * 64 + j * 16 + (lane & 15);
+                Cs[row * CS_PITCH + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    epilogue<bf16_t>(p, Cs, m0, n0);
+}
+
+int launch_fast(const GemmParams& p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_fast_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, CS_BYTES) != hipSuccess)
+            return EAVQA_E_LAUNCH;
+        configured = true;
+    }
+    // XCD grid gx x gy = 8 minimising the panels one XCD touches (rows + cols of its rectangle)
+    int best_gx = 8, best_cost = 1 << 30;
+    const int cand[4] = {8, 4, 2, 1};
+    for (int c = 0; c < 4; ++c) {
+        const int gx = cand[c], gy = 8 / gx;
+        const int cost = (p.tiles_m + gx - 1) / gx + (p.tiles_n + gy - 1) / gy;
+        if (cost < best_cost) { best_cost = cost; best_gx = gx; }
+    }
+    const int gx = best_gx, gy = 8 / gx;
+    const int per_xcd = ((p.tiles_m + gx - 1) / gx) * ((p.tiles_n + gy - 1) / gy);
+    hipLaunchKernelGGL(gemm_bf16_fast_kernel, dim3(per_xcd * 8), dim3(256), CS_BYTES, stream, p, gx, gy);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
 // ================================================================ f32 ===
 constexpr int BK32 = 16;
 constexpr int PITCH32 = 17;                                  // floats per staged row
@@ -386,7 +531,11 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
     return EAVQA_OK;
 }
 
+bool g_disable_fast = false;   // test hook: exercise the general kernel on fast-path shapes
+
 }  // namespace
+
+extern "C" void eavqa_debug_disable_fast_gemm(int disable) { g_disable_fast = disable != 0; }
 
 extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                           const void* A, int64_t lda, const void* B, int64_t ldb,
@@ -423,6 +572,7 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
     p.vec_res = vec_ok(residual, ldr, 4);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
+        if (a_kc && b_kc && (K % FBK) == 0 && !g_disable_fast) return launch_fast(p, s);
         if (a_kc && b_kc) return launch(gemm_bf16_kernel<true, true>, p, s);
         if (a_kc && !b_kc) return launch(gemm_bf16_kernel<true, false>, p, s);
         if (!a_kc && b_kc) return launch(gemm_bf16_kernel<false, true>, p, s);

@@ -84,7 +84,7 @@ class ClipVisionEncoder:
         p = "vision_model."
         W = cfg.width
         K = 3 * cfg.patch * cfg.patch
-        self.kpad = (K + 7) // 8 * 8          # ViT-L/14: K = 588 -> 592 (zero columns contribute nothing)
+        self.kpad = (K + 31) // 32 * 32       # ViT-L/14: K = 588 -> 608 (zero columns contribute nothing)
         wp = torch.zeros((W, self.kpad), dtype=torch.float32)
         wp[:, :K] = state_dict[p + "embeddings.patch_embedding.weight"].reshape(W, K).float().cpu()
         self.w_patch = T(wp)

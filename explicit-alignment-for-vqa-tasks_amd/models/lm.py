@@ -209,7 +209,7 @@ class FrozenCausalLM:
 
     @property
     def vpad(self) -> int:
-        return (self.vocab + 7) // 8 * 8
+        return (self.vocab + 63) // 64 * 64   # K of the lm_head dgrad GEMM: a multiple of the fast path's BK
 
     def _prepare_backward(self) -> None:
         """Transposed weight copies for the dgrad GEMMs (made once, on the first training step)."""

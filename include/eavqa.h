@@ -78,6 +78,10 @@ int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                const void* aux_in, void* aux_out, int64_t ld_aux,
                const float* residual, int64_t ldr, void* stream);
 
+/* Test hook (host, not thread-safe): non-zero routes bf16 k-contiguous GEMMs with K % 32 == 0 through the
+ * general register-staged kernel instead of the LDS-DMA fast path, so that both are covered by parity tests. */
+void eavqa_debug_disable_fast_gemm(int disable);
+
 /* ----------------------------------------------------------- LayerNorm ---
  * torch.nn.LayerNorm over the last dim (ln_1/ln_2/ln_f HF:gpt2 :253-257,620;
  * self_attn_layer_norm/final_layer_norm HF:opt :196-205; CLIP layer_norm1/2, pre/post

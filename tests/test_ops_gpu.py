@@ -43,10 +43,20 @@ ACTS = {
 
 
 # --------------------------------------------------------------------------- GEMM
+@pytest.fixture(params=["fast", "general"])
+def gemm_path(request):
+    """bf16 k-contiguous GEMMs with K % 32 == 0 take the LDS-DMA fast kernel; run every case through both."""
+    from eavqa_amd import _lib
+    _lib.load().eavqa_debug_disable_fast_gemm(int(request.param == "general"))
+    yield request.param
+    _lib.load().eavqa_debug_disable_fast_gemm(0)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (1, 8, 8), (64, 520, 1032), (300, 50257 // 64, 128)])
-def test_gemm_layouts_and_edges(ops, dtype, a_kc, b_kc, M, N, K):
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (1, 8, 8), (64, 520, 1032), (300, 50257 // 64, 128),
+                                   (2688, 1280, 1280), (130, 3000, 32), (257, 129, 96)])
+def test_gemm_layouts_and_edges(ops, gemm_path, dtype, a_kc, b_kc, M, N, K):
     vec = 8 if dtype == torch.bfloat16 else 4
     if (not a_kc and M % vec) or (not b_kc and N % vec):
         pytest.skip("contiguous dim must be a multiple of the vector width (checked in test_gemm_rejects)")
@@ -73,7 +83,7 @@ def test_gemm_identity_asymmetric(ops, dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("act", ["none", "tanh", "relu", "gelu_new", "quick_gelu"])
-def test_gemm_epilogue_forward(ops, dtype, act):
+def test_gemm_epilogue_forward(ops, gemm_path, dtype, act):
     M, N, K = 150, 264, 96
     a, b = rnd(M, K, dtype=dtype, seed=3, scale=0.3), rnd(N, K, dtype=dtype, seed=4, scale=0.3)
     bias = rnd(N, seed=5)
@@ -122,7 +132,7 @@ def test_gemm_rejects_bad_arguments(ops):
         ops.gemm(torch.zeros(4, 8), torch.zeros(4, 8))          # CPU tensors: no fallback
 
 
-def test_gemm_large_bf16_statistical(ops):
+def test_gemm_large_bf16_statistical(ops, gemm_path):
     """A real-shape bf16 GEMM (GPT-2-large c_fc on one batch): relative Frobenius error vs fp64."""
     M, N, K = 2688, 5120, 1280
     a, b = rnd(M, K, dtype=torch.bfloat16, seed=11), rnd(N, K, dtype=torch.bfloat16, seed=12, scale=0.02)
