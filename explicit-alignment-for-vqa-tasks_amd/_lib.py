@@ -25,13 +25,15 @@ SIGNATURES = {
     "eavqa_check_device": [],
     "eavqa_gemm": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i32, f32, ptr, i32, ptr, ptr, i64, ptr, i64, ptr],
     "eavqa_debug_disable_fast_gemm": [i32],
+    "eavqa_debug_gemm_stagger": [i32],
     "eavqa_layernorm_fwd": [i32, i32, i32, i32, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, ptr, ptr],
-    "eavqa_layernorm_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr],
-    "eavqa_attention_fwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i64, i32, f32, ptr, ptr],
+    "eavqa_layernorm_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, ptr],
+    "eavqa_attention_fwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i64, ptr, i32, f32, ptr, ptr],
     "eavqa_attention_bwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64,
-                            ptr, i64, ptr, i64, ptr, i64, ptr, i32, f32, ptr, ptr, ptr],
+                            ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, f32, ptr, ptr, ptr],
     "eavqa_build_prefix_rows": [i32, i32, i32, ptr, ptr, i32, i32, i32, ptr, ptr, ptr, ptr],
     "eavqa_build_fewshot_rows": [i32, i32, i32, i32, i64, ptr, ptr, i32, ptr, ptr, ptr, ptr, ptr],
+    "eavqa_build_row_plan": [i32, i32, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "eavqa_copy_rows": [i32, i32, i32, i32, ptr, i64, i64, ptr, i64, i64, i64, ptr],
     "eavqa_colsum": [i32, i32, i32, ptr, i64, ptr, i32, ptr],
     "eavqa_embed_assemble": [i32, i32, i32, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr],
@@ -43,9 +45,9 @@ SIGNATURES = {
     "eavqa_adamw": [i64, ptr, ptr, ptr, ptr, i32, f32, f32, f32, f32, f32, f32, i32, ptr, ptr],
     "eavqa_patchify": [i32, i32, i32, i32, ptr, ptr, i64, ptr],
     "eavqa_vit_assemble": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, i64, ptr],
-    "eavqa_cast_rows": [i32, i32, i32, ptr, i64, ptr, i64, ptr],
+    "eavqa_cast_rows": [i32, i32, i64, ptr, i64, ptr, i64, ptr],
 }
-_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_debug_disable_fast_gemm": None}
+_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_debug_disable_fast_gemm": None, "eavqa_debug_gemm_stagger": None}
 
 _lib = None
 

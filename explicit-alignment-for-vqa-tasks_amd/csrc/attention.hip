@@ -22,9 +22,11 @@ struct AttnParams {
     void* dq; void* dk; void* dv;
     int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     const int32_t* key_mask;
+    const int32_t* cu;   // packed self-attention: sample b owns rows [cu[b], cu[b+1]) of q/k/v/o (Sq = Sk = that length)
     float* lse; float* delta;
     int B, H, Sq, Sk, hd, causal, tile;
     int64_t ld_mask;
+    int stat_ld;         // row pitch of lse / delta: [B, H, stat_ld]
     int64_t bsq, bsk;   // rows between consecutive batches of q/o/do/dq and of k/v/dk/dv
     float scale;
 };
@@ -62,6 +64,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int r_local = threadIdx.x / LPR, part = threadIdx.x % LPR;
     const int r0 = blockIdx.x * ROWS;
+    if (p.cu) {                                 // packed: this sample's own length and row base
+        const int base = p.cu[b], len = p.cu[b + 1] - base;
+        if (r0 >= len) return;
+        p.Sq = p.Sk = len;
+        p.bsq = p.bsk = 0;
+        const int64_t skip_q = (int64_t)base;
+        p.q = reinterpret_cast<const T*>(p.q) + skip_q * p.ldq;
+        p.k = reinterpret_cast<const T*>(p.k) + skip_q * p.ldk;
+        p.v = reinterpret_cast<const T*>(p.v) + skip_q * p.ldv;
+        p.out = reinterpret_cast<T*>(p.out) + skip_q * p.ldo;
+    }
     const int i = r0 + r_local;                 // query row
     const bool active = i < p.Sq;
     const int off = p.Sk - p.Sq;                // causal: key j visible iff j <= i + off
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         for (int d = 0; d < DP4; ++d)
             elem<T>::st4(O + ((int64_t)b * p.bsq + i) * p.ldo + head_off + dbase + 4 * d,
                          make_float4(acc[d].x * inv, acc[d].y * inv, acc[d].z * inv, acc[d].w * inv));
-        if (p.lse && part == 0) p.lse[((int64_t)b * p.H + h) * p.Sq + i] = m + logf(l);
+        if (p.lse && part == 0) p.lse[((int64_t)b * p.H + h) * p.stat_ld + i] = m + logf(l);
     }
 }
 
@@ -158,6 +171,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int r_local = threadIdx.x / LPR, part = threadIdx.x % LPR;
     const int r0 = blockIdx.x * ROWS;
+    if (p.cu) {
+        const int base = p.cu[b], len = p.cu[b + 1] - base;
+        if (r0 >= len) return;
+        p.Sq = p.Sk = len;
+        p.bsq = p.bsk = 0;
+        const int64_t skip = (int64_t)base;
+        p.q = reinterpret_cast<const T*>(p.q) + skip * p.ldq;
+        p.k = reinterpret_cast<const T*>(p.k) + skip * p.ldk;
+        p.v = reinterpret_cast<const T*>(p.v) + skip * p.ldv;
+        p.o = reinterpret_cast<const T*>(p.o) + skip * p.ldo;
+        p.d_o = reinterpret_cast<const T*>(p.d_o) + skip * p.lddo;
+        p.dq = reinterpret_cast<T*>(p.dq) + skip * p.lddq;
+    }
     const int i = r0 + r_local;
     const bool active = i < p.Sq;
     const int off = p.Sk - p.Sq;
@@ -182,7 +208,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         dq[d] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float delta = group_sum<LPR>(dsum);
-    const int64_t stat = ((int64_t)b * p.H + h) * p.Sq + i;
+    const int64_t stat = ((int64_t)b * p.H + h) * p.stat_ld + i;
     const float lse = active ? p.lse[stat] : 0.f;
     if (active && part == 0) p.delta[stat] = delta;
 
@@ -241,6 +267,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int r_local = threadIdx.x / LPR, part = threadIdx.x % LPR;
     const int j0 = blockIdx.x * ROWS;
+    if (p.cu) {
+        const int base = p.cu[b], len = p.cu[b + 1] - base;
+        if (j0 >= len) return;
+        p.Sq = p.Sk = len;
+        p.bsq = p.bsk = 0;
+        const int64_t skip = (int64_t)base;
+        p.q = reinterpret_cast<const T*>(p.q) + skip * p.ldq;
+        p.k = reinterpret_cast<const T*>(p.k) + skip * p.ldk;
+        p.v = reinterpret_cast<const T*>(p.v) + skip * p.ldv;
+        p.d_o = reinterpret_cast<const T*>(p.d_o) + skip * p.lddo;
+        p.dk = reinterpret_cast<T*>(p.dk) + skip * p.lddk;
+        p.dv = reinterpret_cast<T*>(p.dv) + skip * p.lddv;
+    }
     const int j = j0 + r_local;                 // key row
     const bool active = j < p.Sk;
     const int off = p.Sk - p.Sq;
@@ -274,7 +313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         stage_rows<T>(DOs, DO, p.lddo, (int64_t)b * p.bsq, q0, p.Sq, p.tile, p.hd, head_off);
         for (int c = threadIdx.x; c < p.tile; c += blockDim.x) {
             const bool in = q0 + c < p.Sq;
-            const int64_t st = ((int64_t)b * p.H + h) * p.Sq + q0 + c;
+            const int64_t st = ((int64_t)b * p.H + h) * p.stat_ld + q0 + c;
             stats[c] = in ? p.lse[st] : 0.f;
             stats[p.tile + c] = in ? p.delta[st] : 0.f;
         }
@@ -379,7 +418,8 @@ extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int 
                                    const void* q, int64_t ldq, const void* k, int64_t ldk,
                                    const void* v, int64_t ldv, void* o, int64_t ldo,
                                    int64_t q_batch_rows, int64_t kv_batch_rows,
-                                   const int32_t* key_mask, int64_t ld_mask, int causal, float scale, float* lse, void* stream) {
+                                   const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal,
+                                   float scale, float* lse, void* stream) {
     if (!q || !k || !v || !o) return EAVQA_E_ARG;
     int rc = check_common(dtype, B, H, Sq, Sk, hd);
     if (rc) return rc;
@@ -388,6 +428,8 @@ extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int 
     p.q = q; p.k = k; p.v = v; p.out = o; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.key_mask = key_mask; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.hd = hd;
     p.causal = causal; p.scale = scale;
+    p.cu = cu_seqlens; p.stat_ld = Sq;
+    if (cu_seqlens && (key_mask || Sq != Sk)) return EAVQA_E_ARG;
     p.ld_mask = ld_mask > 0 ? ld_mask : Sk;
     if (p.ld_mask < Sk) return EAVQA_E_ARG;
     p.bsq = q_batch_rows > 0 ? q_batch_rows : Sq;
@@ -402,7 +444,7 @@ extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int 
                                    const void* v, int64_t ldv, const void* o, int64_t ldo,
                                    const void* d_o, int64_t lddo,
                                    void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
-                                   const int32_t* key_mask, int causal, float scale,
+                                   const int32_t* key_mask, const int32_t* cu_seqlens, int causal, float scale,
                                    const float* lse, float* delta, void* stream) {
     if (!q || !k || !v || !o || !d_o || !dq || !dk || !dv || !lse || !delta) return EAVQA_E_ARG;
     int rc = check_common(dtype, B, H, Sq, Sk, hd);
@@ -413,7 +455,8 @@ extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int 
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.key_mask = key_mask; p.lse = const_cast<float*>(lse); p.delta = delta;
     p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.hd = hd; p.causal = causal; p.scale = scale;
-    p.bsq = Sq; p.bsk = Sk; p.ld_mask = Sk;
+    p.bsq = Sq; p.bsk = Sk; p.ld_mask = Sk; p.cu = cu_seqlens; p.stat_ld = Sq;
+    if (cu_seqlens && (key_mask || Sq != Sk)) return EAVQA_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     rc = dtype == EAVQA_F32 ? dispatch<float>(K_DQ, p, s) : dispatch<bf16_t>(K_DQ, p, s);
     if (rc) return rc;

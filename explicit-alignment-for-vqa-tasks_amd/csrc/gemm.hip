@@ -19,6 +19,10 @@
 
 namespace {
 
+bool g_disable_fast = false;   // test hook: exercise the general kernel on fast-path shapes
+int g_stagger = 0;             // experiment knob: s_sleep units for odd co-resident blocks of the fast kernel
+int g_ablate = 0;              // experiment knob: ablation variant of the fast kernel (timing only)
+
 struct GemmParams {
     const void* A; const void* B; void* C;
     const float* bias; const void* aux_in; void* aux_out; const float* residual;
@@ -282,10 +286,54 @@ __device__ __forceinline__ bool fast_tile(const GemmParams& p, int gx, int gy, i
     return true;
 }
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, int gx, int gy) {
+// one pipeline step: tile t is already in registers (fragment set P); tile t+1 is fetched from its LDS stage
+// into set P^1 while the 16 MFMAs of tile t run, and the DMA of tile t+4 is issued into the stage tile t
+// occupied (its fragments left LDS during the previous step).
+#define EAVQA_FAST_STEP(P, t)                                                                         \
+    {                                                                                                 \
+        const int rem = nk - 2 - (t);             /* tiles issued after t+1 */                         \
+        /* fragment set P (read during the previous step) is complete; unconditional so that the      */ \
+        /* compiler's own lgkmcnt bookkeeping sees it on every path and adds no drain before the MFMAs */ \
+        /* sched_barrier: MFMAs are register-only, so the scheduler would otherwise sink the previous  */ \
+        /* step's MFMAs below this wait (draining the reads that were just issued)                    */ \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0) */                                     \
+        if ((t) + 1 < nk) {                                                                           \
+            /* s_waitcnt simm16 (gfx9): vmcnt [3:0]+[15:14], expcnt [6:4], lgkmcnt [11:8]; the builtin   */ \
+            /* (unlike inline asm) is seen by the compiler's own wait-count bookkeeping                */ \
+            if (ABL < 3) {                                                                            \
+            if (rem >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);        /* vmcnt(8) */                     \
+            else if (rem == 1) __builtin_amdgcn_s_waitcnt(0x0F74);   /* vmcnt(4) */                     \
+            else __builtin_amdgcn_s_waitcnt(0x0F70);                 /* vmcnt(0) */                     \
+            __builtin_amdgcn_s_barrier();                                                             \
+            }                                                                                         \
+            if (ABL < 1 && (t) + 4 < nk) issue((t) + 4);                                              \
+            if (ABL < 2) {                                                                            \
+            const char* st = smem + (((t) + 1) & (FSTAGES - 1)) * FSTAGE;                             \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+                fa[(P) ^ 1][i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+                fb[(P) ^ 1][j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);             \
+            } else {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) { fa[(P) ^ 1][i] = fa[P][i]; fb[(P) ^ 1][i] = fb[P][i]; } \
+            }                                                                                         \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[P][i], fb[P][j], acc[i][j], 0, 0, 0); \
+    }
+
+// ABL (timing experiments only, results are wrong for ABL != 0): 1 = no DMA in the main loop, 2 = also no
+// fragment reads, 3 = also no barrier / waits (bare MFMA loop)
+template <int ABL>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, int gx, int gy, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     if (!fast_tile(p, gx, gy, tm, tn)) return;
+    // two workgroups share a CU and would otherwise run in lockstep (same program, same start): delay every
+    // other one so that one block's MFMA phase overlaps the other's DMA-issue / LDS-read phase
+    if (stagger > 0 && ((blockIdx.x >> 3) & 1))
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(8);
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -324,32 +372,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / FBK;
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-
     const int frow = lane & 15, fk = lane >> 4;
     const int a_off = fswz(wm * 64 + frow, fk);          // + i * 16 rows * 64 B
     const int b_off = FOPER + fswz(wn * 64 + frow, fk);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = nk - 1 - kt;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (kt + 3 < nk) issue(kt + 3);
-        const char* st = smem + (kt & (FSTAGES - 1)) * FSTAGE;
-        bf16x8 af[4], bfr[4];
+    bf16x8 fa[2][4], fb[2][4];
+
+    // prologue: tiles 0..3 in flight, tile 0 into fragment set 0
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 2) issue(2);
+    if (nk > 3) issue(3);
+    if (nk > 3) __builtin_amdgcn_s_waitcnt(0x0F7C);        // vmcnt(12)
+    else if (nk == 3) __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
+    else if (nk == 2) __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
+    else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);
+    for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a_off + i * 1024);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(smem + b_off + j * 1024);
+
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        EAVQA_FAST_STEP(0, t)
+        EAVQA_FAST_STEP(1, t + 1)
     }
+    if (t < nk) EAVQA_FAST_STEP(0, t)
     __syncthreads();   // every wave is done with the ring before it becomes the C staging tile
 
     float* Cs = reinterpret_cast<float*>(smem);
@@ -366,15 +414,22 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
     __syncthreads();
     epilogue<bf16_t>(p, Cs, m0, n0);
 }
+#undef EAVQA_FAST_STEP
+
+typedef void (*fast_kernel_t)(GemmParams, int, int, int);
 
 int launch_fast(const GemmParams& p, hipStream_t stream) {
+    static const fast_kernel_t kernels[4] = {gemm_bf16_fast_kernel<0>, gemm_bf16_fast_kernel<1>, gemm_bf16_fast_kernel<2>,
+                                             gemm_bf16_fast_kernel<3>};
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_fast_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, CS_BYTES) != hipSuccess)
-            return EAVQA_E_LAUNCH;
+        for (int i = 0; i < 4; ++i)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    CS_BYTES) != hipSuccess)
+                return EAVQA_E_LAUNCH;
         configured = true;
     }
+    const fast_kernel_t kernel = kernels[g_ablate & 3];
     // XCD grid gx x gy = 8 minimising the panels one XCD touches (rows + cols of its rectangle)
     int best_gx = 8, best_cost = 1 << 30;
     const int cand[4] = {8, 4, 2, 1};
@@ -385,7 +440,7 @@ int launch_fast(const GemmParams& p, hipStream_t stream) {
     }
     const int gx = best_gx, gy = 8 / gx;
     const int per_xcd = ((p.tiles_m + gx - 1) / gx) * ((p.tiles_n + gy - 1) / gy);
-    hipLaunchKernelGGL(gemm_bf16_fast_kernel, dim3(per_xcd * 8), dim3(256), CS_BYTES, stream, p, gx, gy);
+    hipLaunchKernelGGL(kernel, dim3(per_xcd * 8), dim3(256), CS_BYTES, stream, p, gx, gy, g_stagger);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }
@@ -531,11 +586,11 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
     return EAVQA_OK;
 }
 
-bool g_disable_fast = false;   // test hook: exercise the general kernel on fast-path shapes
 
 }  // namespace
 
 extern "C" void eavqa_debug_disable_fast_gemm(int disable) { g_disable_fast = disable != 0; }
+extern "C" void eavqa_debug_gemm_stagger(int units) { g_stagger = units & 0xff; g_ablate = (units >> 8) & 3; }
 
 extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                           const void* A, int64_t lda, const void* B, int64_t ldb,

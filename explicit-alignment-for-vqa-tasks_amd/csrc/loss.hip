@@ -7,7 +7,10 @@
 
 namespace {
 
+// S > 0: `labels` is the unshifted [B,S] matrix and row r = b*S+s is scored against labels[b, s+1];
+// S == 0: `labels` already holds one (shifted) label per row (packed rows, eavqa_build_row_plan).
 __device__ __forceinline__ int64_t shifted_label(const int64_t* labels, int S, int row) {
+    if (S == 0) return labels[row];
     const int b = row / S, s = row - b * S;
     return (s + 1 < S) ? labels[(int64_t)b * S + s + 1] : -100;
 }
@@ -135,10 +138,10 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(int V, const float* lo
 
 extern "C" int eavqa_ce_fwd(int B, int S, int V, const float* logits, int64_t ld, const int64_t* labels, float* row_loss,
                             float* row_lse, float* loss, float* count, void* stream) {
-    if (B <= 0 || S <= 0 || V <= 0 || !logits || !labels || !row_loss || !row_lse || !loss || !count) return EAVQA_E_ARG;
+    if (B <= 0 || S < 0 || V <= 0 || !logits || !labels || !row_loss || !row_lse || !loss || !count) return EAVQA_E_ARG;
     if (ld < V) return EAVQA_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int rows = B * S;
+    const int rows = S > 0 ? B * S : B;
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, s, S, V, logits, ld, labels, row_loss, row_lse);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, s, rows, S, row_loss, labels, V, loss, count);
     EAVQA_LAUNCH_CHECK();
@@ -148,11 +151,11 @@ extern "C" int eavqa_ce_fwd(int B, int S, int V, const float* logits, int64_t ld
 extern "C" int eavqa_ce_bwd(int dtype, int B, int S, int V, const float* logits, int64_t ld, const int64_t* labels,
                             const float* row_lse, const float* count, const float* gscale, void* dlogits, int64_t ldd,
                             void* stream) {
-    if (B <= 0 || S <= 0 || V <= 0 || !logits || !labels || !row_lse || !count || !gscale || !dlogits) return EAVQA_E_ARG;
+    if (B <= 0 || S < 0 || V <= 0 || !logits || !labels || !row_lse || !count || !gscale || !dlogits) return EAVQA_E_ARG;
     if (ld < V || ldd < V) return EAVQA_E_ARG;
     if (ldd % 4) return EAVQA_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    dim3 grid(B * S, (unsigned)((ldd + 4095) / 4096));
+    dim3 grid(S > 0 ? B * S : B, (unsigned)((ldd + 4095) / 4096));
     if (dtype == EAVQA_F32)
         hipLaunchKernelGGL(ce_bwd_kernel<float>, grid, dim3(256), 0, s, S, V, logits, ld, labels, row_lse, count, gscale, (float*)dlogits, ldd);
     else if (dtype == EAVQA_BF16)

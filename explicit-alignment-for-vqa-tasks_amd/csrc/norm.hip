@@ -71,7 +71,8 @@ template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(int x_f32, int rows, int cols, const void* x, int64_t ldx,
                                                      const T* dy, int64_t lddy, const float* gamma,
                                                      const float* mean, const float* rstd, const float* dres,
-                                                     float* dx, int64_t lddx, float* dgamma, float* dbeta) {
+                                                     float* dx, int64_t lddx, float* dgamma, float* dbeta,
+                                                     T* dx_lowp, int64_t ld_lowp) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int x_f32, int rows, int co
             o.z = r.z + rs * (gd[i].z - m1 - xh[i].z * m2);
             o.w = r.w + rs * (gd[i].w - m1 - xh[i].w * m2);
             *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + 4 * c) = o;
+            if (dx_lowp) elem<T>::st4(dx_lowp + (int64_t)row * ld_lowp + 4 * c, o);
         }
     }
 }
@@ -146,12 +148,13 @@ int ln_fwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, c
 template <typename T>
 int ln_bwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, const void* dy, int64_t lddy,
                     const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
-                    int64_t lddx, float* dgamma, float* dbeta, hipStream_t s) {
+                    int64_t lddx, float* dgamma, float* dbeta, void* dx_lowp, int64_t ld_lowp, hipStream_t s) {
     const int nv = (cols / 4 + 63) / 64;
     dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(256);
 #define EAVQA_LN_BWD(NV)                                                                                   \
     hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, 0, s, x_f32, rows, cols, x, ldx,               \
-                       reinterpret_cast<const T*>(dy), lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta)
+                       reinterpret_cast<const T*>(dy), lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta,  \
+                       reinterpret_cast<T*>(dx_lowp), ld_lowp)
     if (nv <= 2) EAVQA_LN_BWD(2);
     else if (nv <= 4) EAVQA_LN_BWD(4);
     else if (nv <= 8) EAVQA_LN_BWD(8);
@@ -179,14 +182,14 @@ extern "C" int eavqa_layernorm_fwd(int dtype, int x_f32, int rows, int cols, con
 extern "C" int eavqa_layernorm_bwd(int dtype, int x_f32, int rows, int cols, const void* x, int64_t ldx,
                                    const void* dy, int64_t lddy, const float* gamma, const float* mean,
                                    const float* rstd, const float* dres, float* dx, int64_t lddx,
-                                   float* dgamma, float* dbeta, void* stream) {
+                                   float* dgamma, float* dbeta, void* dx_lowp, int64_t ld_lowp, void* stream) {
     if (!x || !dy || !dx || !mean || !rstd || rows <= 0 || cols <= 0) return EAVQA_E_ARG;
     if (cols % 4) return EAVQA_E_SHAPE;
-    if (ldx % 4 || lddy % 4 || lddx % 4) return EAVQA_E_ALIGN;
+    if (ldx % 4 || lddy % 4 || lddx % 4 || (dx_lowp && ld_lowp % 4)) return EAVQA_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_F32)
-        return ln_bwd_dispatch<float>(1, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta, s);
+        return ln_bwd_dispatch<float>(1, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta, dx_lowp, ld_lowp, s);
     if (dtype == EAVQA_BF16)
-        return ln_bwd_dispatch<bf16_t>(x_f32, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta, s);
+        return ln_bwd_dispatch<bf16_t>(x_f32, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta, dx_lowp, ld_lowp, s);
     return EAVQA_E_DTYPE;
 }

@@ -180,9 +180,9 @@ __global__ __launch_bounds__(256) void vit_assemble_kernel(int n_patch, int W, c
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void cast_rows_kernel(int cols, const float* x, int64_t ldx, T* y, int64_t ldy) {
-    const int row = blockIdx.x;
-    for (int c = threadIdx.x * 4; c < cols; c += 256 * 4)
+__global__ __launch_bounds__(256) void cast_rows_kernel(int64_t cols, const float* x, int64_t ldx, T* y, int64_t ldy) {
+    const int row = blockIdx.x;   // blockIdx.y walks 1024-column chunks so that one very long row still fills the chip
+    for (int64_t c = (int64_t)blockIdx.y * 1024 + threadIdx.x * 4; c < cols; c += (int64_t)gridDim.y * 1024)
         elem<T>::st4(y + (int64_t)row * ldy + c, *reinterpret_cast<const float4*>(x + (int64_t)row * ldx + c));
 }
 
@@ -219,12 +219,64 @@ __global__ __launch_bounds__(256) void colsum_kernel(int rows, int cols, const T
     }
 }
 
+// Row plan for the training forward: keep only attended positions (mask != 0) of each sample, in order.
+// One 256-thread block: per-sample counts -> exclusive scan (cu_seqlens) -> per-sample compaction.
+__global__ __launch_bounds__(256) void row_plan_kernel(int B, int S, int pack, const int32_t* mask, const int64_t* labels,
+                                                       const int32_t* src, const int32_t* pos, int32_t* cu, int32_t* src_p,
+                                                       int32_t* pos_p, int64_t* row_labels, int32_t* flat_index) {
+    extern __shared__ int counts[];          // [B + 1]
+    for (int b = threadIdx.x; b < B; b += 256) {
+        int c = S;
+        if (pack) {
+            c = 0;
+            for (int s = 0; s < S; ++s) c += mask[(int64_t)b * S + s] != 0 ? 1 : 0;
+        }
+        counts[b + 1] = c;
+    }
+    if (threadIdx.x == 0) counts[0] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int b = 1; b <= B; ++b) counts[b] += counts[b - 1];   // B <= a few hundred: serial scan is fine
+    __syncthreads();
+    for (int b = threadIdx.x; b <= B; b += 256) cu[b] = counts[b];
+    // one wave per sample walks its row with a running offset
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int b = wave; b < B; b += 4) {
+        int carry = counts[b];
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const int keep = (s < S) && (!pack || mask[(int64_t)b * S + s] != 0) ? 1 : 0;
+            const int inc = wave_iscan(keep) + carry;
+            if (keep) {
+                const int r = inc - 1;
+                const int64_t f = (int64_t)b * S + s;
+                src_p[r] = src[f];
+                pos_p[r] = pos[f];
+                flat_index[r] = (int32_t)f;
+                if (row_labels) row_labels[r] = (labels && s + 1 < S) ? labels[f + 1] : -100;   // shift (loss_utils.py:61-63)
+            }
+            carry = __shfl(inc, 63, 64);
+        }
+    }
+}
+
 __global__ void zero_kernel(int n, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = 0.f;
 }
 
 }  // namespace
+
+extern "C" int eavqa_build_row_plan(int B, int S, int pack, const int32_t* mask, const int64_t* labels, const int32_t* src,
+                                    const int32_t* pos, int32_t* cu_seqlens, int32_t* src_rows, int32_t* pos_rows,
+                                    int64_t* row_labels, int32_t* flat_index, void* stream) {
+    if (B <= 0 || S <= 0 || !mask || !src || !pos || !cu_seqlens || !src_rows || !pos_rows || !flat_index) return EAVQA_E_ARG;
+    if ((size_t)(B + 1) * 4 > 60 * 1024) return EAVQA_E_SHAPE;
+    hipLaunchKernelGGL(row_plan_kernel, dim3(1), dim3(256), (size_t)(B + 1) * 4, reinterpret_cast<hipStream_t>(stream), B, S, pack,
+                       mask, labels, src, pos, cu_seqlens, src_rows, pos_rows, row_labels, flat_index);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
 
 extern "C" int eavqa_copy_rows(int dtype, int B, int S, int cols, const void* src, int64_t lds, int64_t src_batch_rows,
                                void* dst, int64_t ldd, int64_t dst_batch_rows, int64_t dst_row0, void* stream) {
@@ -354,14 +406,19 @@ extern "C" int eavqa_vit_assemble(int dtype, int B, int n_patch, int W, const vo
     return EAVQA_OK;
 }
 
-extern "C" int eavqa_cast_rows(int dtype, int rows, int cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream) {
+extern "C" int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream) {
     if (rows <= 0 || cols <= 0 || !x || !y) return EAVQA_E_ARG;
     if (cols % 4 || ldx % 4 || ldy % 4) return EAVQA_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int64_t chunks = (cols + 1023) / 1024;
+    const int64_t want = (2048 + rows - 1) / rows;          // ~2048 blocks in total
+    if (chunks > want) chunks = want;
+    if (chunks > 65535) chunks = 65535;
+    dim3 grid(rows, (unsigned)chunks);
     if (dtype == EAVQA_F32)
-        hipLaunchKernelGGL(cast_rows_kernel<float>, dim3(rows), dim3(256), 0, s, cols, x, ldx, (float*)y, ldy);
+        hipLaunchKernelGGL(cast_rows_kernel<float>, grid, dim3(256), 0, s, cols, x, ldx, (float*)y, ldy);
     else if (dtype == EAVQA_BF16)
-        hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, cols, x, ldx, (bf16_t*)y, ldy);
+        hipLaunchKernelGGL(cast_rows_kernel<bf16_t>, grid, dim3(256), 0, s, cols, x, ldx, (bf16_t*)y, ldy);
     else return EAVQA_E_DTYPE;
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;

@@ -319,7 +319,8 @@ class _PrefixLMLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, prefix_rows, lm: FrozenCausalLM, src, pos, mask, labels, B, S, holder):
-        out = lm.forward(prefix_rows, src, pos, mask, B, S, labels=labels, save=True)
+        out = lm.forward(prefix_rows, src, pos, mask, B, S, labels=labels, save=True, pack=holder.pop("pack", False),
+                         lengths=holder.pop("lengths", None))
         ctx.lm, ctx.tape, ctx.n_rows = lm, out["tape"], prefix_rows.shape[0]
         holder.update(out)
         return out["loss"].view(())
@@ -332,8 +333,26 @@ class _PrefixLMLoss(torch.autograd.Function):
         return (d,) + (None,) * 8
 
 
-class _Output(SimpleNamespace):
-    """``.loss`` and ``.logits`` like HF's ``CausalLMOutputWithCrossAttentions`` (clipcap.py:337-342)."""
+class _Output:
+    """``.loss`` and ``.logits`` like HF's ``CausalLMOutputWithCrossAttentions`` (clipcap.py:337-342).
+    ``.logits`` [B, L+T, V] float32 is assembled on first access: after a packed forward the padded positions (whose
+    reference logits are never used: no loss, never attended) read as zeros."""
+
+    def __init__(self, loss, rows_logits, B, S, V, flat_index=None):
+        self.loss = loss
+        self._lg, self._B, self._S, self._V, self._flat = rows_logits, B, S, V, flat_index
+        self._full = None
+
+    @property
+    def logits(self):
+        if self._full is None:
+            if self._flat is None:
+                self._full = self._lg.view(self._B, self._S, -1)[:, :, :self._V]
+            else:
+                full = torch.zeros((self._B * self._S, self._V), device=self._lg.device, dtype=self._lg.dtype)
+                full[self._flat.long()] = self._lg[:, :self._V]
+                self._full = full.view(self._B, self._S, self._V)
+        return self._full
 
 
 # =========================================================================== models
@@ -370,7 +389,8 @@ class ClipCaptionModel(nn.Module):
             self.clip_project = MLP((prefix_size, (E * prefix_length) // 2, E * prefix_length), device=device, dtype=dtype)
         else:
             self.clip_project = TransformerMapper(prefix_size, E, prefix_length, clip_length, num_layers, device=device, dtype=dtype)
-        self._holder: dict = {}
+        # training forward drops padded positions before the first GEMM (exact for loss / gradients / attended logits)
+        self.pack_padding = True
 
     # -- helpers ----------------------------------------------------------------------------
     def get_dummy_token(self, batch_size: int, num_question_tokens: int, device) -> Tensor:
@@ -391,9 +411,10 @@ class ClipCaptionModel(nn.Module):
 
     # -- training forward --------------------------------------------------------------------
     def forward(self, question_tokens: Tensor, prefix: Tensor, question_mask: Optional[Tensor] = None,
-                labels: Optional[Tensor] = None, pad_token_id: Optional[int] = None):
+                labels: Optional[Tensor] = None, pad_token_id: Optional[int] = None, question_lengths=None):
         """``forward`` clipcap.py:290-342 -> object with ``.loss`` (0-d, differentiable w.r.t. the mapper)
-        and ``.logits`` [B, L+T, V] float32."""
+        and ``.logits`` [B, L+T, V] float32.  ``question_lengths`` (optional host ints: attended tokens per row,
+        i.e. ``question_mask.sum(1)``) spares the packed path one device->host read."""
         dev = self.device_
         B, T = question_tokens.shape
         L = self.prefix_length
@@ -402,16 +423,23 @@ class ClipCaptionModel(nn.Module):
         qm = question_mask.to(dev) if question_mask is not None else torch.ones_like(tok)
         rows, stride, off = self._project(prefix.to(dev))
         src, mask, pos = ops.build_prefix_rows(tok, qm, L, self.gpt.cfg.pos_mode, stride, off)
-        out = _Output(loss=None, logits=None)
         if labels is not None:
             full = torch.cat((self.get_dummy_token(B, 0, dev), labels.to(dev)), dim=1).contiguous()   # :323-335
-            holder: dict = {}
-            out.loss = _PrefixLMLoss.apply(rows, self.gpt, src, pos, mask, full, B, S, holder)
-            lg = holder["logits"]
-        else:
-            lg = self.gpt.forward(rows, src, pos, mask, B, S, logits="all")["logits"]
-        out.logits = lg.view(B, S, -1)[:, :, :self.gpt.vocab]
-        return out
+            pack = bool(self.pack_padding and self.training)
+            lengths = None
+            if pack:
+                if question_lengths is None:
+                    if question_mask is None:
+                        question_lengths = [T] * B
+                    elif not question_mask.is_cuda:
+                        question_lengths = (question_mask != 0).sum(1).tolist()     # host tensor: free
+                if question_lengths is not None:
+                    lengths = [L + int(n) for n in question_lengths]
+            holder: dict = {"pack": pack, "lengths": lengths}
+            loss = _PrefixLMLoss.apply(rows, self.gpt, src, pos, mask, full, B, S, holder)
+            return _Output(loss, holder["logits"], B, S, self.gpt.vocab, holder["flat_index"] if pack else None)
+        lg = self.gpt.forward(rows, src, pos, mask, B, S, logits="all")["logits"]
+        return _Output(None, lg, B, S, self.gpt.vocab)
 
     # -- generation --------------------------------------------------------------------------
     @torch.no_grad()

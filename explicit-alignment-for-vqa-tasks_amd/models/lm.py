@@ -251,17 +251,31 @@ class FrozenCausalLM:
 
     # ---------------------------------------------------------------- forward
     def forward(self, prefix_rows: Optional[Tensor], src: Tensor, pos: Tensor, mask: Tensor, B: int, S: int, *,
-                labels: Optional[Tensor] = None, save: bool = False, logits: str = "none"):
+                labels: Optional[Tensor] = None, save: bool = False, logits: str = "none", pack: bool = False,
+                lengths=None):
         """Run the decoder over ``B`` rows of ``S`` positions.
 
         ``src/pos/mask``: int32 [B,S] from ``ops.build_prefix_rows`` / ``build_fewshot_rows``;
         ``prefix_rows``: mapper output rows in the compute dtype.  ``logits``: "none" | "all" | "last".
-        Returns a dict with ``loss``/``count`` (when labels), ``logits`` ([B*S or B, vpad] fp32) and,
-        when ``save``, the tape for :meth:`backward`.
+        ``pack``: drop the padded positions (mask == 0) before the first GEMM (``eavqa_build_row_plan``): the loss
+        and every attended position are unchanged, the work shrinks from B*S to sum(lengths) rows.  ``lengths``
+        (host ints, attended positions per sample) saves the one device->host read of the packed row count.
+        Returns a dict with ``loss``/``count`` (when labels), ``logits`` ([rows or B, vpad] fp32; with ``pack`` also
+        ``flat_index`` mapping packed rows to b*S+s) and, when ``save``, the tape for :meth:`backward`.
         """
         c, T = self.cfg, self.dtype
-        E, H, hd, M = c.n_embd, c.n_head, c.head_dim, B * S
+        E, H, hd = c.n_embd, c.n_head, c.head_dim
         scale = hd ** -0.5
+        cu = flat = row_labels = None
+        M = B * S
+        if pack:
+            cu, src_r, pos_r, row_labels, flat = ops.build_row_plan(mask, labels, src, pos, True)
+            M = int(sum(lengths)) if lengths is not None else int(cu[-1].item())
+            src, pos, flat = src_r[:M], pos_r[:M], flat[:M]
+            row_labels = row_labels[:M] if labels is not None else None
+            attn_mask = None
+        else:
+            attn_mask = mask
         x = ops.embed_assemble(src, pos, self.wte, prefix_rows, self.wpe)
         tape = [] if save else None
         for L in self.layers:
@@ -272,9 +286,10 @@ class FrozenCausalLM:
             qkv = ops.gemm(a, L.w_qkv, bias=L.b_qkv)
             q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
             if save:
-                ctx, lse = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=mask, causal=True, scale=scale, save_lse=True)
+                ctx, lse = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=attn_mask, causal=True, scale=scale,
+                                             save_lse=True, cu_seqlens=cu)
             else:
-                ctx = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=mask, causal=True, scale=scale)
+                ctx = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=attn_mask, causal=True, scale=scale, cu_seqlens=cu)
             x1 = ops.gemm(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True)
             if save:
                 a2, mean2, rstd2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T, save_stats=True)
@@ -287,8 +302,8 @@ class FrozenCausalLM:
             if save:
                 tape.append((x, mean1, rstd1, qkv, ctx, lse, x1, mean2, rstd2, u))
             x = x2
-        out = {}
-        if logits == "last" and labels is None:
+        out = {"rows": M, "flat_index": flat}
+        if logits == "last" and labels is None and not pack:
             xl = x.view(B, S, E)[:, -1]                       # strided rows: only the last position is normalised
             hf = ops.layernorm_fwd(xl, self.lnf_g, self.lnf_b, c.eps, T)
             out["logits"] = self._head(hf)
@@ -302,13 +317,12 @@ class FrozenCausalLM:
             lg = self._head(hf)
             out["logits"] = lg
             if labels is not None:
-                loss, count, row_lse = ops.ce_fwd(lg, labels, self.vocab)
+                ce_labels = row_labels if pack else labels
+                loss, count, row_lse = ops.ce_fwd(lg, ce_labels, self.vocab)
                 out["loss"], out["count"] = loss, count
                 if save:
-                    out["tape"] = dict(layers=tape, x_last=x, meanf=meanf, rstdf=rstdf, logits=lg, labels=labels,
-                                       row_lse=row_lse, count=count, src=src, mask=mask, B=B, S=S)
-        if logits == "last":
-            out["logits_last"] = out["logits"].view(B, S, -1)[:, -1]
+                    out["tape"] = dict(layers=tape, x_last=x, meanf=meanf, rstdf=rstdf, logits=lg, labels=ce_labels,
+                                       row_lse=row_lse, count=count, src=src, mask=attn_mask, cu=cu, B=B, S=S, M=M)
         return out
 
     def _head(self, hf: Tensor) -> Tensor:
@@ -323,29 +337,28 @@ class FrozenCausalLM:
         self._prepare_backward()
         c, T = self.cfg, self.dtype
         E, H, hd = c.n_embd, c.n_head, c.head_dim
-        B, S = tape["B"], tape["S"]
-        M = B * S
+        B, S, M = tape["B"], tape["S"], tape["M"]
         scale = hd ** -0.5
-        mask = tape["mask"]
+        mask, cu = tape["mask"], tape["cu"]
         lowp = T != torch.float32
 
-        def as_T(t):   # fp32 gradient of the residual stream -> GEMM operand dtype
-            return ops.cast_rows(t, T) if lowp else t
-
+        # the residual-stream gradient lives in fp32 (dx); each LayerNorm backward also emits the copy in the
+        # compute dtype that the next dgrad GEMM consumes as its A operand (no separate cast pass)
         dlog = ops.ce_bwd(tape["logits"], tape["labels"], self.vocab, tape["row_lse"], tape["count"], gloss, T, self.vpad)
         dhf = ops.gemm(dlog, self.head_t)                                   # [M,E]
-        dx = ops.layernorm_bwd(tape["x_last"], dhf, self.lnf_g, tape["meanf"], tape["rstdf"])
+        dxT = torch.empty((M, E), device=self.device, dtype=T) if lowp else None
+        dx = ops.layernorm_bwd(tape["x_last"], dhf, self.lnf_g, tape["meanf"], tape["rstdf"], lowp_out=dxT)
         for L, (x, mean1, rstd1, qkv, ctx, lse, x1, mean2, rstd2, u) in zip(reversed(self.layers), reversed(tape["layers"])):
-            du = ops.gemm(as_T(dx), L.w_fc2_t, act=c.act, aux_in=u)          # (dx W2) * act'(u)   [M,F]
+            du = ops.gemm(dxT if lowp else dx, L.w_fc2_t, act=c.act, aux_in=u)   # (dx W2) * act'(u)   [M,F]
             da2 = ops.gemm(du, L.w_fc1_t)                                    # [M,E]
-            dx1 = ops.layernorm_bwd(x1, da2, L.ln2_g, mean2, rstd2, dres=dx, out=dx)
-            dctx = ops.gemm(as_T(dx1), L.w_o_t)                              # [M,E]
+            dx1 = ops.layernorm_bwd(x1, da2, L.ln2_g, mean2, rstd2, dres=dx, out=dx, lowp_out=dxT)
+            dctx = ops.gemm(dxT if lowp else dx1, L.w_o_t)                   # [M,E]
             dqkv = torch.empty_like(qkv)
             q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
             ops.attention_bwd(q, k, v, ctx, dctx, lse, B, H, S, S, hd, key_mask=mask, causal=True, scale=scale,
-                              dq=dqkv[:, :E], dk=dqkv[:, E:2 * E], dv=dqkv[:, 2 * E:])
+                              dq=dqkv[:, :E], dk=dqkv[:, E:2 * E], dv=dqkv[:, 2 * E:], cu_seqlens=cu)
             da = ops.gemm(dqkv, L.w_qkv_t)                                   # [M,E]
-            dx = ops.layernorm_bwd(x, da, L.ln1_g, mean1, rstd1, dres=dx1, out=dx1)
+            dx = ops.layernorm_bwd(x, da, L.ln1_g, mean1, rstd1, dres=dx1, out=dx1, lowp_out=dxT)
         return ops.embed_assemble_bwd(tape["src"], dx, n_prefix_rows, T)
 
 

@@ -86,39 +86,45 @@ def layernorm_fwd(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ep
 
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], mean: Tensor, rstd: Tensor,
                   dres: Optional[Tensor] = None, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
-                  out: Optional[Tensor] = None) -> Tensor:
+                  out: Optional[Tensor] = None, lowp_out: Optional[Tensor] = None) -> Tensor:
+    """``lowp_out``: optional [rows, cols] tensor in ``dy.dtype`` that receives a second copy of dx."""
     _dev(x)
     rows, cols = x.shape
     dx = out if out is not None else torch.empty((rows, cols), device=x.device, dtype=torch.float32)
     if dres is not None and _ld(dres) != _ld(dx):
         raise _lib.EavqaError("dres must share dx's leading dimension")
     call("eavqa_layernorm_bwd", dtype_id(dy.dtype), int(x.dtype == torch.float32), rows, cols, _p(x), _ld(x), _p(dy), _ld(dy),
-         _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _ld(dx), _p(dgamma), _p(dbeta), _stream())
+         _p(gamma), _p(mean), _p(rstd), _p(dres), _p(dx), _ld(dx), _p(dgamma), _p(dbeta), _p(lowp_out),
+         _ld(lowp_out) if lowp_out is not None else 0, _stream())
     return dx
 
 
 def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, H: int, Sq: int, Sk: int, hd: int, *,
                   key_mask: Optional[Tensor] = None, causal: bool = False, scale: float = 1.0, save_lse: bool = False,
-                  q_batch_rows: int = 0, kv_batch_rows: int = 0, ld_mask: int = 0, out: Optional[Tensor] = None):
-    """``q``: rows [B*Sq, >=H*hd] views (element (b,s,h,d) at row b*Sq+s, col h*hd+d); same for k/v."""
+                  q_batch_rows: int = 0, kv_batch_rows: int = 0, ld_mask: int = 0, out: Optional[Tensor] = None,
+                  cu_seqlens: Optional[Tensor] = None):
+    """``q``: rows [B*Sq, >=H*hd] views (element (b,s,h,d) at row b*Sq+s, col h*hd+d); same for k/v.
+    With ``cu_seqlens`` the rows are packed (sample b = rows cu[b]..cu[b+1]) and ``Sq`` is the longest sample."""
     _dev(q)
-    o = out if out is not None else torch.empty((B * Sq, H * hd), device=q.device, dtype=q.dtype)
+    o = out if out is not None else torch.empty((q.shape[0] if cu_seqlens is not None else B * Sq, H * hd), device=q.device, dtype=q.dtype)
     lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32) if save_lse else None
     call("eavqa_attention_fwd", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o),
-         q_batch_rows, kv_batch_rows, _p(key_mask), ld_mask, int(causal), float(scale), _p(lse), _stream())
+         q_batch_rows, kv_batch_rows, _p(key_mask), ld_mask, _p(cu_seqlens), int(causal), float(scale), _p(lse), _stream())
     return (o, lse) if save_lse else o
 
 
 def attention_bwd(q, k, v, o, d_o, lse, B, H, Sq, Sk, hd, *, key_mask=None, causal=False, scale=1.0,
-                  dq=None, dk=None, dv=None):
+                  dq=None, dk=None, dv=None, cu_seqlens=None):
     _dev(q)
-    dq = dq if dq is not None else torch.empty((B * Sq, H * hd), device=q.device, dtype=q.dtype)
-    dk = dk if dk is not None else torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
-    dv = dv if dv is not None else torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
+    nq = q.shape[0] if cu_seqlens is not None else B * Sq
+    nk = k.shape[0] if cu_seqlens is not None else B * Sk
+    dq = dq if dq is not None else torch.empty((nq, H * hd), device=q.device, dtype=q.dtype)
+    dk = dk if dk is not None else torch.empty((nk, H * hd), device=q.device, dtype=q.dtype)
+    dv = dv if dv is not None else torch.empty((nk, H * hd), device=q.device, dtype=q.dtype)
     delta = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
     call("eavqa_attention_bwd", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o),
-         _p(d_o), _ld(d_o), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(key_mask), int(causal), float(scale),
-         _p(lse), _p(delta), _stream())
+         _p(d_o), _ld(d_o), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(key_mask), _p(cu_seqlens), int(causal),
+         float(scale), _p(lse), _p(delta), _stream())
     return dq, dk, dv
 
 
@@ -180,11 +186,33 @@ def build_labels(input_ids: Tensor, L: int, pad_token_id: int, bos_token_id: int
     return out
 
 
+def build_row_plan(mask: Tensor, labels: Optional[Tensor], src: Tensor, pos: Tensor, pack: bool):
+    """-> (cu_seqlens [B+1], src_rows, pos_rows, row_labels, flat_index), the row buffers sized B*S (first
+    ``cu_seqlens[-1]`` entries valid)."""
+    _dev(mask)
+    B, S = mask.shape
+    dev = mask.device
+    cu = torch.empty(B + 1, device=dev, dtype=torch.int32)
+    src_r = torch.empty(B * S, device=dev, dtype=torch.int32)
+    pos_r = torch.empty(B * S, device=dev, dtype=torch.int32)
+    flat = torch.empty(B * S, device=dev, dtype=torch.int32)
+    lab = torch.empty(B * S, device=dev, dtype=torch.int64)
+    call("eavqa_build_row_plan", B, S, int(pack), _p(mask), _p(labels), _p(src), _p(pos), _p(cu), _p(src_r), _p(pos_r), _p(lab),
+         _p(flat), _stream())
+    return cu, src_r, pos_r, lab, flat
+
+
+def _ce_dims(labels: Tensor):
+    """(B, S, rows): 2-D labels = unshifted [B,S]; 1-D labels = one shifted label per row (S = 0)."""
+    if labels.dim() == 2:
+        return labels.shape[0], labels.shape[1], labels.shape[0] * labels.shape[1]
+    return labels.shape[0], 0, labels.shape[0]
+
+
 def ce_fwd(logits: Tensor, labels: Tensor, V: int):
-    """logits float32 [B*S, ld>=V]; labels int64 [B,S] unshifted -> (loss[1], count[1], row_lse)."""
+    """logits float32 [rows, ld>=V]; labels int64 [B,S] unshifted or [rows] shifted -> (loss[1], count[1], row_lse)."""
     _dev(logits)
-    B, S = labels.shape
-    rows = B * S
+    B, S, rows = _ce_dims(labels)
     row_loss = torch.empty(rows, device=logits.device, dtype=torch.float32)
     row_lse = torch.empty(rows, device=logits.device, dtype=torch.float32)
     loss = torch.empty(1, device=logits.device, dtype=torch.float32)
@@ -195,8 +223,8 @@ def ce_fwd(logits: Tensor, labels: Tensor, V: int):
 
 def ce_bwd(logits: Tensor, labels: Tensor, V: int, row_lse: Tensor, count: Tensor, gscale: Tensor, dtype: torch.dtype,
            ldd: int) -> Tensor:
-    B, S = labels.shape
-    d = torch.empty((B * S, ldd), device=logits.device, dtype=dtype)
+    B, S, rows = _ce_dims(labels)
+    d = torch.empty((rows, ldd), device=logits.device, dtype=dtype)
     call("eavqa_ce_bwd", dtype_id(dtype), B, S, V, _p(logits), _ld(logits), _p(labels), _p(row_lse), _p(count), _p(gscale),
          _p(d), ldd, _stream())
     return d

@@ -81,6 +81,9 @@ int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
 /* Test hook (host, not thread-safe): non-zero routes bf16 k-contiguous GEMMs with K % 32 == 0 through the
  * general register-staged kernel instead of the LDS-DMA fast path, so that both are covered by parity tests. */
 void eavqa_debug_disable_fast_gemm(int disable);
+/* Experiment knob (host): start-up delay, in units of 8 x 64 cycles, of every other co-resident workgroup of the
+ * fast GEMM kernel (0 = none). */
+void eavqa_debug_gemm_stagger(int units);
 
 /* ----------------------------------------------------------- LayerNorm ---
  * torch.nn.LayerNorm over the last dim (ln_1/ln_2/ln_f HF:gpt2 :253-257,620;
@@ -93,12 +96,13 @@ int eavqa_layernorm_fwd(int dtype, int x_f32, int rows, int cols, const void* x,
                         const float* gamma, const float* beta, float eps,
                         void* y, int64_t ldy, float* mean, float* rstd, void* stream);
 /* dx[r,:] = (dres ? dres[r,:] : 0) + LayerNorm'(dy)[r,:]   (float32 out; dres may alias dx)
- * dgamma/dbeta: float32 [cols], ACCUMULATED with atomics when non-NULL (mapper only). */
+ * dgamma/dbeta: float32 [cols], ACCUMULATED with atomics when non-NULL (mapper only).
+ * dx_lowp: optional second copy of dx in `dtype` (the next dgrad GEMM's A operand), or NULL. */
 int eavqa_layernorm_bwd(int dtype, int x_f32, int rows, int cols, const void* x, int64_t ldx,
                         const void* dy, int64_t lddy, const float* gamma,
                         const float* mean, const float* rstd,
                         const float* dres, float* dx, int64_t lddx,
-                        float* dgamma, float* dbeta, void* stream);
+                        float* dgamma, float* dbeta, void* dx_lowp, int64_t ld_lowp, void* stream);
 
 /* ----------------------------------------------------------- attention ---
  * softmax(scale * q k^T + mask) v per (batch, head); eager formula
@@ -110,6 +114,9 @@ int eavqa_layernorm_bwd(int dtype, int x_f32, int rows, int cols, const void* x,
  * key_mask: int32, row b at key_mask + b*ld_mask (ld_mask 0 = Sk), 0 = padded key; or NULL.  causal: key j visible to query i iff
  * j <= i + (Sk - Sq).  Masked scores are replaced by -FLT_MAX (HF adds finfo.min), so a
  * fully masked row yields the uniform average over all Sk keys, never NaN.
+ * cu_seqlens: int32 [B+1] or NULL.  Non-NULL = packed self-attention over rows with the padding removed
+ * (eavqa_build_row_plan): sample b owns rows [cu[b], cu[b+1]) of q/k/v/o, Sq = Sk = that length (the Sq
+ * argument is then the LONGEST sample, used for the grid and the lse pitch), key_mask must be NULL.
  * lse: float32 [B,H,Sq] log-sum-exp of the scaled masked scores (NULL in inference).
  * hd in {4,8,16,32,48,64,80,96,128,160,256,320,512}.
  */
@@ -117,7 +124,8 @@ int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,
                         const void* q, int64_t ldq, const void* k, int64_t ldk,
                         const void* v, int64_t ldv, void* o, int64_t ldo,
                         int64_t q_batch_rows, int64_t kv_batch_rows,
-                        const int32_t* key_mask, int64_t ld_mask, int causal, float scale, float* lse, void* stream);
+                        const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal, float scale,
+                        float* lse, void* stream);
 /* Backward (dense batches only: batch_rows = Sq / Sk): dq/dk/dv in `dtype`, addressed as q/k/v
  * with leading dims lddq/lddk/lddv.
  * delta: float32 scratch [B,H,Sq] (rowsum(do*o), written by the call). */
@@ -126,7 +134,7 @@ int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int hd,
                         const void* v, int64_t ldv, const void* o, int64_t ldo,
                         const void* d_o, int64_t lddo,
                         void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
-                        const int32_t* key_mask, int causal, float scale,
+                        const int32_t* key_mask, const int32_t* cu_seqlens, int causal, float scale,
                         const float* lse, float* delta, void* stream);
 
 /* ---------------------------------------- sequence assembly (indexing) ---
@@ -150,6 +158,16 @@ int eavqa_build_prefix_rows(int B, int L, int T, const int64_t* tokens, const in
 int eavqa_build_fewshot_rows(int B, int T, int L, int n_img, int64_t special_token_id,
                              const int64_t* tokens, const int64_t* question_mask, int pos_mode,
                              int32_t* src, int32_t* mask_out, int32_t* pos, int32_t* status, void* stream);
+/* Row plan of the training forward.  pack != 0 drops every position whose mask is 0 (padding): because of the
+ * causal + key-padding mask (HF:gpt2 :54-72) and ignore_index -100 such positions influence neither the loss nor
+ * any attended position, so the loss and the mapper gradients are unchanged while every GEMM / LayerNorm /
+ * attention runs on sum(lengths) rows instead of B*S.  pack == 0 keeps all B*S rows (identity plan).
+ * Inputs: mask/src/pos int32 [B,S] (eavqa_build_prefix_rows), labels int64 [B,S] UNshifted or NULL.
+ * Outputs: cu_seqlens int32 [B+1]; for each kept row r (sample-major, position order): src_rows[r], pos_rows[r],
+ * flat_index[r] = b*S+s, row_labels[r] = labels[b, s+1] (or -100 at s = S-1 / labels NULL), buffers sized B*S. */
+int eavqa_build_row_plan(int B, int S, int pack, const int32_t* mask, const int64_t* labels, const int32_t* src,
+                         const int32_t* pos, int32_t* cu_seqlens, int32_t* src_rows, int32_t* pos_rows,
+                         int64_t* row_labels, int32_t* flat_index, void* stream);
 /* dst[(b*dst_batch_rows + dst_row0 + s)*ldd + c] = src[(b*src_batch_rows + s)*lds + c], b < B, s < S,
  * c < cols (`dtype` -> `dtype`): fills / appends the per-layer KV cache [B, S_max, E] from the QKV
  * projection rows (the reference re-runs the whole sequence instead, clipcap.py:414-419). cols % 4 == 0. */
@@ -177,7 +195,8 @@ int eavqa_build_labels(int mode, int B, int T, int L, const int64_t* input_ids, 
 /* -------------------------------------------------------- loss / argmax ---
  * ForCausalLMLoss HF:loss/loss_utils.py:49-71: labels shifted left by one, ignore_index -100,
  * mean over kept positions.  logits float32 [rows, ld] (first V columns valid), labels int64 [B,S]
- * UNshifted (rows = B*S, row r = b*S+s is scored against labels[b, s+1]).
+ * UNshifted (rows = B*S, row r = b*S+s is scored against labels[b, s+1]); or, with S == 0, `labels` is one
+ * already-shifted label per row (int64 [B], B = number of rows; packed rows of eavqa_build_row_plan).
  * Writes row_loss/row_lse float32 [rows] (0 for ignored rows), then loss[0] = sum/count and
  * count[0] (deterministic tree reduction, no atomics). */
 int eavqa_ce_fwd(int B, int S, int V, const float* logits, int64_t ld, const int64_t* labels,
@@ -213,7 +232,7 @@ int eavqa_vit_assemble(int dtype, int B, int n_patch, int W, const void* patch_e
                        const float* cls, const float* pos, float* x, int64_t ldx, void* stream);
 
 /* float32 -> `dtype` elementwise copy with row strides (casts the residual stream / pooled rows). */
-int eavqa_cast_rows(int dtype, int rows, int cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream);
+int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream);
 
 #ifdef __cplusplus
 }

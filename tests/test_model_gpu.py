@@ -49,14 +49,25 @@ def build_model(z, arch, mapping_type, dtype):
     ("gpt2", "transformer", "clipcap_gpt2_transformer.npz"),
     ("opt", "mlp", "clipcap_opt_mlp.npz"),
 ])
-def test_forward_loss_logits_and_mapper_grads_match_reference(dtype, arch, mapping_type, fixture):
+@pytest.mark.parametrize("pack", [False, True])
+def test_forward_loss_logits_and_mapper_grads_match_reference(dtype, arch, mapping_type, fixture, pack):
+    """pack=True is the default training path (padded positions dropped before the first GEMM): loss, gradients and
+    the logits of every attended position must still match the reference; pack=False also matches the (unused)
+    logits the reference computes at padded positions."""
     z = load_golden(fixture)
     model = build_model(z, arch, mapping_type, dtype).train()
+    model.pack_padding = pack
     out = model(question_tokens=T(z["ids"]), prefix=T(z["prefix"]), question_mask=T(z["mask"]), labels=T(z["labels"]),
                 pad_token_id=int(z["pad_id"]))
     tol = TOL[dtype]
     assert out.logits.shape == z["logits"].shape
-    assert (out.logits.float().cpu() - T(z["logits"])).abs().max().item() <= tol["logits"]
+    diff = (out.logits.float().cpu() - T(z["logits"])).abs()
+    if pack:
+        L = z["logits"].shape[1] - z["mask"].shape[1]
+        attended = torch.cat([torch.ones(z["mask"].shape[0], L, dtype=torch.bool), T(z["mask"]) != 0], dim=1)
+        assert (out.logits.float().cpu()[~attended] == 0).all()
+        diff = diff[attended]
+    assert diff.max().item() <= tol["logits"]
     assert abs(out.loss.item() - float(z["loss"])) <= tol["loss"]
     out.loss.backward()
     for k, g in sub(z, "g.").items():
@@ -157,9 +168,30 @@ def test_real_shape_gpt2_small_fp32_logits_within_1e3_of_oracle():
     ids = ids * mask + 50256 * (1 - mask)
     labels = oracle.label_mask_cc(ids, 50256)
     prefix = torch.randn(B, 512, generator=g)
+    model.pack_padding = False
     out = model(question_tokens=ids, prefix=prefix, question_mask=mask, labels=labels)
     mapper = {k: v.detach().cpu() for k, v in model.clip_project.state_dict().items()}
     ocfg = dict(arch="gpt2", n_layer=cfg.n_layer, n_head=cfg.n_head)
     loss, logits = oracle.clipcap_forward(sd, ocfg, mapper, dict(prefix_length=10, mapping_type="mlp"), ids, prefix, mask, labels)
     assert (out.logits.cpu() - logits).abs().max().item() <= 1e-3
     assert abs(out.loss.item() - loss.item()) <= 1e-4
+
+
+def test_packed_and_padded_training_steps_agree_fp32():
+    """Dropping the padded rows changes neither the loss nor the mapper gradients (beyond fp32 summation order),
+    with the lengths given by the host or read back from the device."""
+    z = load_golden("clipcap_gpt2_mlp.npz")
+    model = build_model(z, "gpt2", "mlp", torch.float32).train()
+    args = dict(question_tokens=T(z["ids"]), prefix=T(z["prefix"]), question_mask=T(z["mask"]), labels=T(z["labels"]))
+    res = {}
+    for name, pack, kw in (("padded", False, {}), ("packed_host_lengths", True, {}),
+                           ("packed_device_lengths", True, dict(question_mask=T(z["mask"]).to(DEV)))):
+        model.pack_padding = pack
+        model.clip_project.zero_grad(set_to_none=True)
+        out = model(**{**args, **kw})
+        out.loss.backward()
+        res[name] = (out.loss.item(), {k: p.grad.clone() for k, p in model.clip_project.named_parameters()})
+    for name in ("packed_host_lengths", "packed_device_lengths"):
+        assert abs(res[name][0] - res["padded"][0]) <= 1e-6
+        for k, g in res["padded"][1].items():
+            assert torch.allclose(res[name][1][k], g, atol=1e-6, rtol=1e-5), (name, k)

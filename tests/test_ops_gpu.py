@@ -435,3 +435,58 @@ def test_patchify_and_vit_assemble(ops, dtype, img, ps):
     x = ops.vit_assemble(pe.to(DEV), cls.to(DEV), pos.to(DEV), B, g * g).cpu().view(B, g * g + 1, W)
     ref = torch.cat([cls.expand(B, 1, W), pe.float().view(B, g * g, W)], dim=1) + pos[None]
     assert torch.equal(x, ref)
+
+
+# --------------------------------------------------------------------------- packed rows
+def test_row_plan_and_packed_attention_match_padded(ops):
+    g = torch.Generator().manual_seed(7)
+    B, S, H, hd = 4, 37, 2, 16
+    E = H * hd
+    lens = torch.tensor([37, 5, 20, 1])
+    mask = (torch.arange(S)[None] < lens[:, None]).int()
+    src = torch.randint(0, 100, (B, S), generator=g).int()
+    pos = torch.arange(S).expand(B, S).int().contiguous()
+    labels = torch.randint(0, 50, (B, S), generator=g)
+    cu, src_r, pos_r, lab_r, flat = ops.build_row_plan(mask.to(DEV), labels.to(DEV), src.to(DEV), pos.to(DEV), True)
+    M = int(lens.sum())
+    assert cu.cpu().tolist() == [0, 37, 42, 62, 63]
+    keep = mask.bool().flatten()
+    exp_flat = torch.arange(B * S)[keep]
+    assert torch.equal(flat.cpu()[:M].long(), exp_flat)
+    assert torch.equal(src_r.cpu()[:M], src.flatten()[keep]) and torch.equal(pos_r.cpu()[:M], pos.flatten()[keep])
+    shifted = torch.nn.functional.pad(labels, (0, 1), value=-100)[:, 1:]
+    assert torch.equal(lab_r.cpu()[:M], shifted.flatten()[keep])
+    # identity plan
+    cu0, src0, _, lab0, flat0 = ops.build_row_plan(mask.to(DEV), labels.to(DEV), src.to(DEV), pos.to(DEV), False)
+    assert cu0.cpu().tolist() == [0, 37, 74, 111, 148] and torch.equal(flat0.cpu().long(), torch.arange(B * S))
+    assert torch.equal(lab0.cpu(), shifted.flatten())
+    # packed attention == padded attention on the kept rows (forward and backward)
+    qkv = rnd(B * S, 3 * E, seed=3).to(DEV)
+    do = rnd(B * S, E, seed=4).to(DEV)
+    o, lse = ops.attention_fwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], B, H, S, S, hd, key_mask=mask.to(DEV), causal=True,
+                               scale=0.25, save_lse=True)
+    dq, dk, dv = ops.attention_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], o, do, lse, B, H, S, S, hd,
+                                   key_mask=mask.to(DEV), causal=True, scale=0.25)
+    idx = flat[:M].long()
+    qp = qkv[idx].contiguous()
+    dop = do[idx].contiguous()
+    op, lsep = ops.attention_fwd(qp[:, :E], qp[:, E:2 * E], qp[:, 2 * E:], B, H, S, S, hd, causal=True, scale=0.25,
+                                 save_lse=True, cu_seqlens=cu)
+    assert torch.allclose(op, o[idx], atol=1e-6)
+    dqp, dkp, dvp = ops.attention_bwd(qp[:, :E], qp[:, E:2 * E], qp[:, 2 * E:], op, dop, lsep, B, H, S, S, hd, causal=True,
+                                      scale=0.25, cu_seqlens=cu)
+    # gradients flowing from padded QUERY rows do not exist in the packed run: zero them in the padded reference
+    do_masked = do.clone()
+    do_masked[~keep.to(DEV)] = 0
+    dq2, dk2, dv2 = ops.attention_bwd(qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:], o, do_masked, lse, B, H, S, S, hd,
+                                      key_mask=mask.to(DEV), causal=True, scale=0.25)
+    assert torch.allclose(dqp, dq2[idx], atol=1e-5) and torch.allclose(dkp, dk2[idx], atol=1e-5) and torch.allclose(dvp, dv2[idx], atol=1e-5)
+
+
+def test_cross_entropy_with_row_labels(ops):
+    V, rows = 50, 9
+    logits = (rnd(rows, 56, seed=1) * 2).to(DEV)
+    lab = torch.tensor([3, -100, 7, 49, -100, 0, 1, 2, -100]).to(DEV)
+    loss, count, row_lse = ops.ce_fwd(logits, lab, V)
+    ref = torch.nn.functional.cross_entropy(logits.cpu()[:, :V], lab.cpu(), ignore_index=-100)
+    assert abs(loss.item() - ref.item()) <= 1e-5 and count.item() == 6

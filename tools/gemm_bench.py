@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Per-shape timing of eavqa_gemm on the hot path's shapes (cfg2: M = 64 x 42 = 2688).
+
+    python tools/gemm_bench.py [--iters 50] [--general]
+
+Prints TFLOP/s per (M, N, K) from HIP events around `iters` back-to-back launches on random data.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from eavqa_amd import _lib, ops
+
+SHAPES = [  # (M, N, K, what)
+    (2688, 3840, 1280, "qkv fwd"), (2688, 1280, 1280, "proj fwd / dctx"), (2688, 5120, 1280, "fc1 fwd / du"),
+    (2688, 1280, 5120, "fc2 fwd / da2"), (2688, 1280, 3840, "dqkv->da"), (2688, 50257, 1280, "lm_head fwd"),
+    (2688, 1280, 50304, "lm_head dgrad"), (3200, 2304, 768, "vit qkv"), (3200, 768, 768, "vit proj"),
+    (3200, 3072, 768, "vit fc1"), (3200, 768, 3072, "vit fc2"), (4096, 4096, 4096, "square 4k"), (8192, 8192, 8192, "square 8k"),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--general", action="store_true", help="force the general (register-staged) kernel")
+    ap.add_argument("--epilogue", action="store_true", help="bias + gelu_new + aux_out like fc1")
+    ap.add_argument("--stagger", type=int, default=0)
+    ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation variant of the fast kernel (wrong results)")
+    ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
+    args = ap.parse_args()
+    _lib.load().eavqa_debug_disable_fast_gemm(int(args.general))
+    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8))
+    dev = "cuda"
+    only = [w for w in args.only.split(",") if w]
+    for M, N, K, what in SHAPES:
+        if only and not any(w in what for w in only):
+            continue
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16)
+        b = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        kw = {}
+        if args.epilogue:
+            kw = dict(bias=torch.zeros(N, device=dev), act="gelu_new", aux_out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        for _ in range(3):
+            ops.gemm(a, b, out=out, **kw)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = max(5, min(args.iters, int(2e12 / (2.0 * M * N * K)) + 5))
+        e0.record()
+        for _ in range(iters):
+            ops.gemm(a, b, out=out, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        print(f"{what:18s} M={M:5d} N={N:6d} K={K:6d}  {us:9.1f} us  {2.0*M*N*K/us/1e6:8.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
