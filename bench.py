@@ -68,7 +68,10 @@ def build_workload(name, dtype, device, rank):
                               lm=lm, dtype=dtype, device=device).train()
     opt = FusedAdamW(model.clip_project.flat, lr=1e-4)
     pad = lcfg.eos_token_id
-    batch = cc_batch(w["batch"], lcfg.vocab, pad, image_size=vcfg.image, max_len=w["text_len"], seed=2021 + rank, device=device)
+    batch = cc_batch(w["batch"], lcfg.vocab, pad, image_size=vcfg.image, max_len=w["text_len"], seed=2021 + rank, device="cpu")
+    lengths = batch["attention_mask"].sum(1).tolist()      # host-side metadata of the collate (caption lengths)
+    batch = {k: v.to(device) for k, v in batch.items()}
+    batch["question_lengths"] = lengths
     return w, vcfg, lcfg, vit, model, opt, batch, pad
 
 
@@ -92,7 +95,7 @@ class Stepper:
         emb = self.vit.encode_image(b["pixel_values"])          # independent of the mapper: overlaps the exchange
         self._apply_update()                                     # AdamW of the previous step
         out = self.model(question_tokens=b["input_ids"], prefix=emb, question_mask=b["attention_mask"], labels=b["labels"],
-                         pad_token_id=self.pad)
+                         pad_token_id=self.pad, question_lengths=b["question_lengths"])
         out.loss.backward()
         self.sync.start()
         self.pending_update = True

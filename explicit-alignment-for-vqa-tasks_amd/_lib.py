@@ -26,6 +26,7 @@ SIGNATURES = {
     "eavqa_gemm": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i32, f32, ptr, i32, ptr, ptr, i64, ptr, i64, ptr],
     "eavqa_debug_disable_fast_gemm": [i32],
     "eavqa_debug_gemm_stagger": [i32],
+    "eavqa_debug_attention_valu": [i32],
     "eavqa_layernorm_fwd": [i32, i32, i32, i32, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, ptr, ptr],
     "eavqa_layernorm_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, ptr],
     "eavqa_attention_fwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i64, ptr, i32, f32, ptr, ptr],
@@ -47,7 +48,7 @@ SIGNATURES = {
     "eavqa_vit_assemble": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, i64, ptr],
     "eavqa_cast_rows": [i32, i32, i64, ptr, i64, ptr, i64, ptr],
 }
-_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_debug_disable_fast_gemm": None, "eavqa_debug_gemm_stagger": None}
+_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_debug_disable_fast_gemm": None, "eavqa_debug_gemm_stagger": None, "eavqa_debug_attention_valu": None}
 
 _lib = None
 

@@ -11,8 +11,11 @@
 // Masking: a masked score is REPLACED by -FLT_MAX (HF adds finfo.min to a score that is
 // negligible against it), so a fully masked row degrades to the uniform average, never NaN.
 #include "common.h"
+#include "attention_mfma.hip"   // bf16 matrix-core kernels (same translation unit)
 
 namespace {
+
+bool g_force_valu = false;   // test hook: keep bf16 on the vector-ALU kernels
 
 constexpr int CK = 8;  // keys per softmax chunk
 
@@ -436,8 +439,18 @@ extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int 
     p.bsk = kv_batch_rows > 0 ? kv_batch_rows : Sk;
     if (p.bsq < Sq || p.bsk < Sk) return EAVQA_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_BF16 && eavqa_attn_mfma::supported(hd) && !g_force_valu) {
+        eavqa_attn_mfma::Params m = {};
+        m.q = q; m.k = k; m.v = v; m.out = o; m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo;
+        m.key_mask = key_mask; m.ld_mask = p.ld_mask; m.cu = cu_seqlens; m.lse = lse;
+        m.B = B; m.H = H; m.Sq = Sq; m.Sk = Sk; m.hd = hd; m.causal = causal; m.stat_ld = Sq;
+        m.bsq = p.bsq; m.bsk = p.bsk; m.scale = scale;
+        return eavqa_attn_mfma::run(0, m, s);
+    }
     return dtype == EAVQA_F32 ? dispatch<float>(K_FWD, p, s) : dispatch<bf16_t>(K_FWD, p, s);
 }
+
+extern "C" void eavqa_debug_attention_valu(int force) { g_force_valu = force != 0; }
 
 extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int hd,
                                    const void* q, int64_t ldq, const void* k, int64_t ldk,
@@ -458,6 +471,17 @@ extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int 
     p.bsq = Sq; p.bsk = Sk; p.ld_mask = Sk; p.cu = cu_seqlens; p.stat_ld = Sq;
     if (cu_seqlens && (key_mask || Sq != Sk)) return EAVQA_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_BF16 && eavqa_attn_mfma::supported(hd) && !g_force_valu) {
+        eavqa_attn_mfma::Params m = {};
+        m.q = q; m.k = k; m.v = v; m.o = o; m.d_o = d_o; m.dq = dq; m.dk = dk; m.dv = dv;
+        m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo; m.lddo = lddo; m.lddq = lddq; m.lddk = lddk; m.lddv = lddv;
+        m.key_mask = key_mask; m.ld_mask = Sk; m.cu = cu_seqlens; m.lse = const_cast<float*>(lse); m.delta = delta;
+        m.B = B; m.H = H; m.Sq = Sq; m.Sk = Sk; m.hd = hd; m.causal = causal; m.stat_ld = Sq;
+        m.bsq = Sq; m.bsk = Sk; m.scale = scale;
+        rc = eavqa_attn_mfma::run(1, m, s);
+        if (rc) return rc;
+        return eavqa_attn_mfma::run(2, m, s);
+    }
     rc = dtype == EAVQA_F32 ? dispatch<float>(K_DQ, p, s) : dispatch<bf16_t>(K_DQ, p, s);
     if (rc) return rc;
     return dtype == EAVQA_F32 ? dispatch<float>(K_DKV, p, s) : dispatch<bf16_t>(K_DKV, p, s);

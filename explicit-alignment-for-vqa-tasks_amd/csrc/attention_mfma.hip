@@ -1,0 +1,399 @@
+// bf16 attention forward / backward on the matrix cores (v_mfma_f32_16x16x32_bf16), head dims 64 / 80 /
+// 96 / 128.  Called from eavqa_attention_fwd / _bwd (attention.hip) for dtype bf16; the fp32 path and the
+// other head dims stay on the vector-ALU kernels.
+//
+// One workgroup = 4 waves = 64 "lane items" of one (batch, head); a wave owns 16 of them, ONE PER LANE
+// COLUMN (lane & 15), and streams the other sequence dimension ("register items") through LDS in tiles
+// of 64.  Every product is oriented so that the register items are the MFMA row index:
+//   forward / dQ pass : lane item = query, register item = key
+//        S^T  = K  . Q^T      (A = K rows from LDS,        B = Q fragment held in registers)
+//        O^T += V^T . P^T     (A = V^T from LDS,           B = P^T = the S^T accumulator itself)
+//        dP^T = V  . dO^T,    dQ^T += K^T . dS^T
+//   dK/dV pass        : lane item = key, register item = query
+//        S = Q . K^T, dP = dO . V^T, dV^T += dO^T . P, dK^T += Q^T . dS
+// An accumulator tile (rows in registers, column on the lane) is directly the B operand of the next
+// product that sums over its ROW index, so P / dS never leave registers: registers 0-3 of two adjacent
+// 16-row tiles form one 8-element B fragment; the A operand (read from a TRANSPOSED LDS image [d][item])
+// is fetched in the same permuted k order (two 8-byte reads).  Softmax statistics are per lane column:
+// the reduction over register items is in-lane plus two wave shuffles (xor 16, 32).
+// Masked scores are replaced by -FLT_MAX exactly as in the vector-ALU kernels.
+#include "common.h"
+
+namespace eavqa_attn_mfma {
+
+struct Params {
+    const void* q; const void* k; const void* v; const void* o; const void* d_o;
+    void* out; void* dq; void* dk; void* dv;
+    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    const int32_t* key_mask; int64_t ld_mask;
+    const int32_t* cu;
+    float* lse; float* delta;
+    int B, H, Sq, Sk, hd, causal, stat_ld;
+    int64_t bsq, bsk;
+    float scale;
+};
+
+constexpr int TILE = 64;
+
+template <int KS> struct Geo {
+    static constexpr int HP = KS * 32;              // head dim padded to the MFMA k step
+    static constexpr int PR = HP * 2 + 16;          // byte pitch of a row-major [item][d] image (16 B pad: bank spread)
+    static constexpr int PT = TILE * 2 + 8;         // byte pitch of a transposed [d][item] image
+    static constexpr int ROW_BYTES = TILE * PR;
+    static constexpr int TR_BYTES = HP * PT;
+};
+
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (bf16_t)0.f;
+    return z;
+}
+
+// Stage 64 rows (items row0 .. row0+63 of the current sample/head) into a row-major and/or a transposed image.
+template <int KS>
+__device__ __forceinline__ void stage(char* rowmaj, char* transposed, const bf16_t* src, int64_t ld, int row0, int n_rows,
+                                      int hd, int head_off) {
+    constexpr int CH = Geo<KS>::HP / 8;             // 16-byte chunks per row
+    for (int c = threadIdx.x; c < TILE * CH; c += 256) {
+        const int r = c / CH, ch = c - r * CH;
+        uint4 val = make_uint4(0u, 0u, 0u, 0u);
+        if (row0 + r < n_rows && ch * 8 < hd) val = *reinterpret_cast<const uint4*>(src + (int64_t)(row0 + r) * ld + head_off + ch * 8);
+        if (rowmaj) *reinterpret_cast<uint4*>(rowmaj + r * Geo<KS>::PR + ch * 16) = val;
+        if (transposed) {
+            const unsigned w[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned short e = (unsigned short)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu));
+                *reinterpret_cast<unsigned short*>(transposed + (ch * 8 + i) * Geo<KS>::PT + r * 2) = e;
+            }
+        }
+    }
+}
+
+// B fragments of a lane item (one sequence row): lane holds d = 32 s + 8 g .. +7 of row `row`
+template <int KS>
+__device__ __forceinline__ void load_bfrag(bf16x8 (&f)[KS], const bf16_t* src, int64_t ld, int row, bool valid, int hd,
+                                           int head_off, int g) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int d0 = 32 * s + 8 * g;
+        f[s] = (valid && d0 < hd) ? *reinterpret_cast<const bf16x8*>(src + (int64_t)row * ld + head_off + d0) : zero8();
+    }
+}
+
+// acc[f] (f = 0..3, 16 register items each) = sum_d A_tile[item 16 f + (lane & 15)][d] * bfrag[d]
+template <int KS>
+__device__ __forceinline__ void tile_dot(f32x4 (&acc)[4], const char* rowmaj, const bf16x8 (&bf)[KS], int x, int g) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowmaj + (16 * f + x) * Geo<KS>::PR + (32 * s + 8 * g) * 2);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[s], acc[f], 0, 0, 0);
+        }
+    }
+}
+
+// out[dm] += sum over the 64 register items of T[d = 16 dm + (lane & 15)][item] * w[item], w given as 4 accumulator tiles
+template <int KS, int D16>
+__device__ __forceinline__ void tile_accumulate(f32x4 (&out)[D16], const char* transposed, const f32x4 (&w)[4], int x, int g) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { b[r] = (bf16_t)w[2 * s2][r]; b[4 + r] = (bf16_t)w[2 * s2 + 1][r]; }
+#pragma unroll
+        for (int dm = 0; dm < D16; ++dm) {
+            const char* base = transposed + (16 * dm + x) * Geo<KS>::PT + (32 * s2 + 4 * g) * 2;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(base);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(base + 32);
+            bf16x8 a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
+            out[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, out[dm], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ float group4_sum(float v) { v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64); return v; }
+__device__ __forceinline__ float group4_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+
+// store 4 consecutive d (16 dm + 4 g .. +3) of one row
+__device__ __forceinline__ void store4(bf16_t* dst, int64_t ld, int row, int head_off, int d0, int hd, const f32x4& v, float mul) {
+    if (d0 < hd) elem<bf16_t>::st4(dst + (int64_t)row * ld + head_off + d0, make_float4(v[0] * mul, v[1] * mul, v[2] * mul, v[3] * mul));
+}
+
+// shared prologue: resolve the sample's row window (packed or batched); false = nothing to do for this block
+__device__ __forceinline__ bool window(Params& p, int b, int first_item, bool lanes_are_queries) {
+    if (p.cu) {
+        const int base = p.cu[b], len = p.cu[b + 1] - base;
+        if (first_item >= len) return false;
+        p.Sq = p.Sk = len;
+        p.bsq = p.bsk = base;        // reused as absolute row offsets below
+    } else {
+        if (first_item >= (lanes_are_queries ? p.Sq : p.Sk)) return false;
+        p.bsq = (int64_t)b * p.bsq;
+        p.bsk = (int64_t)b * p.bsk;
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------ forward
+template <int KS, int D16>
+__global__ __launch_bounds__(256) void fwd_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vt = smem + Geo<KS>::ROW_BYTES;
+    int* valid = reinterpret_cast<int*>(Vt + Geo<KS>::TR_BYTES);
+
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * TILE;
+    if (!window(p, b, q0, true)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const int qi = q0 + wave * 16 + x;
+    const bool active = qi < p.Sq;
+    const int off = p.Sk - p.Sq, head_off = h * p.hd;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + p.bsq * p.ldq;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + p.bsk * p.ldk;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + p.bsk * p.ldv;
+
+    bf16x8 qf[KS];
+    load_bfrag<KS>(qf, Q, p.ldq, qi, active, p.hd, head_off, g);
+    f32x4 acc[D16];
+#pragma unroll
+    for (int dm = 0; dm < D16; ++dm) acc[dm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = -FLT_MAX, lsum = 0.f;
+
+    int k_end = p.Sk;
+    if (p.causal) k_end = min(p.Sk, min(p.Sq, q0 + TILE) + off);
+    if (k_end < 1) k_end = min(p.Sk, 1);
+    for (int k0 = 0; k0 < k_end; k0 += TILE) {
+        __syncthreads();
+        stage<KS>(Ks, nullptr, K, p.ldk, k0, p.Sk, p.hd, head_off);
+        stage<KS>(nullptr, Vt, V, p.ldv, k0, p.Sk, p.hd, head_off);
+        for (int c = threadIdx.x; c < TILE; c += 256)
+            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
+        __syncthreads();
+        f32x4 st[4];
+        tile_dot<KS>(st, Ks, qf, x, g);
+        float tmax = -FLT_MAX;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 16 * f + 4 * g + r;          // key within the tile
+                const bool exists = k0 + kk < p.Sk;
+                const bool vis = valid[kk] && (!p.causal || (k0 + kk) <= qi + off);
+                st[f][r] = exists ? (vis ? st[f][r] * p.scale : -FLT_MAX) : -INFINITY;
+                tmax = fmaxf(tmax, st[f][r]);
+            }
+        const float m_new = fmaxf(m, group4_max(tmax));
+        const float corr = __expf(m - m_new);
+        lsum *= corr;
+#pragma unroll
+        for (int dm = 0; dm < D16; ++dm) { acc[dm][0] *= corr; acc[dm][1] *= corr; acc[dm][2] *= corr; acc[dm][3] *= corr; }
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pj = __expf(st[f][r] - m_new);      // exp(-inf) = 0 for keys that do not exist
+                st[f][r] = pj;
+                lsum += pj;
+            }
+        tile_accumulate<KS, D16>(acc, Vt, st, x, g);
+        m = m_new;
+    }
+    const float l = group4_sum(lsum);
+    if (active) {
+        const float inv = 1.f / l;
+        bf16_t* O = reinterpret_cast<bf16_t*>(p.out) + p.bsq * p.ldo;
+#pragma unroll
+        for (int dm = 0; dm < D16; ++dm) store4(O, p.ldo, qi, head_off, 16 * dm + 4 * g, p.hd, acc[dm], inv);
+        if (p.lse && g == 0) p.lse[((int64_t)b * p.H + h) * p.stat_ld + qi] = m + __logf(l);
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward: dQ (+ delta)
+template <int KS, int D16>
+__global__ __launch_bounds__(256) void bwd_dq_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = Ks + Geo<KS>::ROW_BYTES;
+    char* Kt = Vs + Geo<KS>::ROW_BYTES;
+    int* valid = reinterpret_cast<int*>(Kt + Geo<KS>::TR_BYTES);
+
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int q0 = blockIdx.x * TILE;
+    if (!window(p, b, q0, true)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const int qi = q0 + wave * 16 + x;
+    const bool active = qi < p.Sq;
+    const int off = p.Sk - p.Sq, head_off = h * p.hd;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + p.bsq * p.ldq;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + p.bsk * p.ldk;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + p.bsk * p.ldv;
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(p.o) + p.bsq * p.ldo;
+    const bf16_t* DO = reinterpret_cast<const bf16_t*>(p.d_o) + p.bsq * p.lddo;
+
+    bf16x8 qf[KS], dof[KS], of[KS];
+    load_bfrag<KS>(qf, Q, p.ldq, qi, active, p.hd, head_off, g);
+    load_bfrag<KS>(dof, DO, p.lddo, qi, active, p.hd, head_off, g);
+    load_bfrag<KS>(of, O, p.ldo, qi, active, p.hd, head_off, g);
+    float dsum = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsum += (float)dof[s][j] * (float)of[s][j];
+    const float delta = group4_sum(dsum);
+    const int64_t stat = ((int64_t)b * p.H + h) * p.stat_ld + qi;
+    const float lse = active ? p.lse[stat] : 0.f;
+    if (active && g == 0) p.delta[stat] = delta;
+
+    f32x4 dq[D16];
+#pragma unroll
+    for (int dm = 0; dm < D16; ++dm) dq[dm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int k_end = p.Sk;
+    if (p.causal) k_end = min(p.Sk, min(p.Sq, q0 + TILE) + off);
+    if (k_end < 1) k_end = min(p.Sk, 1);
+    for (int k0 = 0; k0 < k_end; k0 += TILE) {
+        __syncthreads();
+        stage<KS>(Ks, Kt, K, p.ldk, k0, p.Sk, p.hd, head_off);
+        stage<KS>(Vs, nullptr, V, p.ldv, k0, p.Sk, p.hd, head_off);
+        for (int c = threadIdx.x; c < TILE; c += 256)
+            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
+        __syncthreads();
+        f32x4 st[4], dp[4];
+        tile_dot<KS>(st, Ks, qf, x, g);
+        tile_dot<KS>(dp, Vs, dof, x, g);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = 16 * f + 4 * g + r;
+                const bool exists = k0 + kk < p.Sk;
+                const bool vis = exists && valid[kk] && (!p.causal || (k0 + kk) <= qi + off);
+                const float pj = exists ? __expf((vis ? st[f][r] * p.scale : -FLT_MAX) - lse) : 0.f;
+                st[f][r] = pj * (dp[f][r] - delta) * p.scale;      // dS^T
+            }
+        tile_accumulate<KS, D16>(dq, Kt, st, x, g);
+    }
+    if (active) {
+        bf16_t* DQ = reinterpret_cast<bf16_t*>(p.dq) + p.bsq * p.lddq;
+#pragma unroll
+        for (int dm = 0; dm < D16; ++dm) store4(DQ, p.lddq, qi, head_off, 16 * dm + 4 * g, p.hd, dq[dm], 1.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------ backward: dK, dV
+template <int KS, int D16>
+__global__ __launch_bounds__(256) void bwd_dkv_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* DOs = Qs + Geo<KS>::ROW_BYTES;
+    char* Qt = DOs + Geo<KS>::ROW_BYTES;
+    char* DOt = Qt + Geo<KS>::TR_BYTES;
+    float* stats = reinterpret_cast<float*>(DOt + Geo<KS>::TR_BYTES);     // lse[64], delta[64]
+
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    const int j0 = blockIdx.x * TILE;
+    if (!window(p, b, j0, false)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const int kj = j0 + wave * 16 + x;                 // this lane's key
+    const bool active = kj < p.Sk;
+    const int off = p.Sk - p.Sq, head_off = h * p.hd;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + p.bsq * p.ldq;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + p.bsk * p.ldk;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + p.bsk * p.ldv;
+    const bf16_t* DO = reinterpret_cast<const bf16_t*>(p.d_o) + p.bsq * p.lddo;
+
+    bf16x8 kf[KS], vf[KS];
+    load_bfrag<KS>(kf, K, p.ldk, kj, active, p.hd, head_off, g);
+    load_bfrag<KS>(vf, V, p.ldv, kj, active, p.hd, head_off, g);
+    const bool kvalid = active && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + kj] != 0);
+    f32x4 dk[D16], dv[D16];
+#pragma unroll
+    for (int dm = 0; dm < D16; ++dm) { dk[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    int q_begin = 0;
+    if (p.causal) q_begin = (max(0, j0 - off) / TILE) * TILE;
+    for (int q0 = q_begin; q0 < p.Sq; q0 += TILE) {
+        __syncthreads();
+        stage<KS>(Qs, Qt, Q, p.ldq, q0, p.Sq, p.hd, head_off);
+        stage<KS>(DOs, DOt, DO, p.lddo, q0, p.Sq, p.hd, head_off);
+        for (int c = threadIdx.x; c < TILE; c += 256) {
+            const bool in = q0 + c < p.Sq;
+            const int64_t st = ((int64_t)b * p.H + h) * p.stat_ld + q0 + c;
+            stats[c] = in ? p.lse[st] : 0.f;
+            stats[TILE + c] = in ? p.delta[st] : 0.f;
+        }
+        __syncthreads();
+        f32x4 sc[4], dp[4];
+        tile_dot<KS>(sc, Qs, kf, x, g);
+        tile_dot<KS>(dp, DOs, vf, x, g);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = 16 * f + 4 * g + r;          // query within the tile
+                const bool exists = q0 + qq < p.Sq;
+                const bool vis = exists && kvalid && (!p.causal || kj <= (q0 + qq) + off);
+                const float pj = exists ? __expf((vis ? sc[f][r] * p.scale : -FLT_MAX) - stats[qq]) : 0.f;
+                sc[f][r] = pj;                                                   // P
+                dp[f][r] = pj * (dp[f][r] - stats[TILE + qq]) * p.scale;        // dS
+            }
+        tile_accumulate<KS, D16>(dv, DOt, sc, x, g);
+        tile_accumulate<KS, D16>(dk, Qt, dp, x, g);
+    }
+    if (active) {
+        bf16_t* DK = reinterpret_cast<bf16_t*>(p.dk) + p.bsk * p.lddk;
+        bf16_t* DV = reinterpret_cast<bf16_t*>(p.dv) + p.bsk * p.lddv;
+#pragma unroll
+        for (int dm = 0; dm < D16; ++dm) {
+            store4(DK, p.lddk, kj, head_off, 16 * dm + 4 * g, p.hd, dk[dm], 1.f);
+            store4(DV, p.lddv, kj, head_off, 16 * dm + 4 * g, p.hd, dv[dm], 1.f);
+        }
+    }
+}
+
+template <int KS, int D16>
+int launch(int which, const Params& p, hipStream_t s) {
+    const size_t row = Geo<KS>::ROW_BYTES, tr = Geo<KS>::TR_BYTES;
+    if (which == 0) {
+        dim3 grid((p.Sq + TILE - 1) / TILE, p.B * p.H);
+        hipLaunchKernelGGL((fwd_kernel<KS, D16>), grid, dim3(256), row + tr + TILE * 4, s, p);
+    } else if (which == 1) {
+        dim3 grid((p.Sq + TILE - 1) / TILE, p.B * p.H);
+        hipLaunchKernelGGL((bwd_dq_kernel<KS, D16>), grid, dim3(256), 2 * row + tr + TILE * 4, s, p);
+    } else {
+        static bool configured = false;        // hd = 128: 2 x 17 KiB + 2 x 17 KiB + stats > 64 KiB
+        const size_t lds = 2 * row + 2 * tr + 2 * TILE * 4;
+        if (lds > 64 * 1024 && !configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkv_kernel<KS, D16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return EAVQA_E_LAUNCH;
+            configured = true;
+        }
+        dim3 grid((p.Sk + TILE - 1) / TILE, p.B * p.H);
+        hipLaunchKernelGGL((bwd_dkv_kernel<KS, D16>), grid, dim3(256), lds, s, p);
+    }
+    if (hipGetLastError() != hipSuccess) return EAVQA_E_LAUNCH;
+    return EAVQA_OK;
+}
+
+bool supported(int hd) { return hd == 64 || hd == 80 || hd == 96 || hd == 128; }
+
+// which: 0 forward, 1 dQ (+delta), 2 dK/dV
+int run(int which, const Params& p, hipStream_t s) {
+    switch (p.hd) {
+        case 64: return launch<2, 4>(which, p, s);
+        case 80: return launch<3, 5>(which, p, s);
+        case 96: return launch<3, 6>(which, p, s);
+        case 128: return launch<4, 8>(which, p, s);
+        default: return EAVQA_E_SHAPE;
+    }
+}
+
+}  // namespace eavqa_attn_mfma

@@ -84,6 +84,8 @@ void eavqa_debug_disable_fast_gemm(int disable);
 /* Experiment knob (host): start-up delay, in units of 8 x 64 cycles, of every other co-resident workgroup of the
  * fast GEMM kernel (0 = none). */
 void eavqa_debug_gemm_stagger(int units);
+/* Test hook (host): non-zero keeps bf16 attention on the vector-ALU kernels instead of the matrix-core ones. */
+void eavqa_debug_attention_valu(int force);
 
 /* ----------------------------------------------------------- LayerNorm ---
  * torch.nn.LayerNorm over the last dim (ln_1/ln_2/ln_f HF:gpt2 :253-257,620;

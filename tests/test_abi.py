@@ -48,7 +48,7 @@ def test_argument_validation_happens_before_any_launch(lib):
     assert lib.eavqa_gemm(1, 1, 1, 8, 8, 12, 16, 16, 16, 16, 16, 8, 0, 1.0, None, 0, None, None, 0, None, 0, None) == -3
     assert lib.eavqa_gemm(1, 1, 1, 8, 8, 8, 18, 8, 16, 8, 16, 8, 0, 1.0, None, 0, None, None, 0, None, 0, None) == -2
     assert lib.eavqa_layernorm_fwd(0, 1, 4, 6, 16, 8, None, None, 1e-5, 16, 8, None, None, None) == -3
-    assert lib.eavqa_attention_fwd(0, 1, 1, 4, 4, 6, 16, 8, 16, 8, 16, 8, 16, 8, 0, 0, None, 0, 0, 1.0, None, None) == -3
+    assert lib.eavqa_attention_fwd(0, 1, 1, 4, 4, 6, 16, 8, 16, 8, 16, 8, 16, 8, 0, 0, None, 0, None, 0, 1.0, None, None) == -3
     assert lib.eavqa_adamw(0, None, None, None, None, 1, 0.1, 0.9, 0.999, 1e-8, 0.01, 1.0, 0, None, None) == -1
 
 

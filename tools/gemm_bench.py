@@ -15,6 +15,8 @@ import torch
 from eavqa_amd import _lib, ops
 
 SHAPES = [  # (M, N, K, what)
+    (2688, 1280, 32, "fixed K=32"), (2688, 1280, 320, "fixed K=320"), (1943, 1280, 1280, "packed proj"), (1943, 3840, 1280, "packed qkv"),
+    (1943, 5120, 1280, "packed fc1"), (1943, 1280, 5120, "packed fc2"),
     (2688, 3840, 1280, "qkv fwd"), (2688, 1280, 1280, "proj fwd / dctx"), (2688, 5120, 1280, "fc1 fwd / du"),
     (2688, 1280, 5120, "fc2 fwd / da2"), (2688, 1280, 3840, "dqkv->da"), (2688, 50257, 1280, "lm_head fwd"),
     (2688, 1280, 50304, "lm_head dgrad"), (3200, 2304, 768, "vit qkv"), (3200, 768, 768, "vit proj"),
