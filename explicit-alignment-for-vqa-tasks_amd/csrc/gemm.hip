@@ -31,7 +31,7 @@ struct GemmParams {
     int act, out_f32;
     float alpha;
     int tiles_m, tiles_n;
-    int vec_c, vec_aux, vec_res;   // 16-byte (8-byte for bf16) vector access allowed on C / aux / residual
+    int vec_c, vec_aux, vec_res, vec_bias;   // 16-byte (8-byte for bf16) vector access allowed on C / aux / residual / bias
 };
 
 constexpr int BM = 128, BN = 128;
@@ -49,18 +49,23 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
     tn = wgid / p.tiles_m;
 }
 
-// ---- epilogue shared by both kernels: Cs holds the 128x128 fp32 tile (pitch CS_PITCH) ----
-template <typename T>
-__device__ __forceinline__ void epilogue(const GemmParams& p, const float* Cs, int m0, int n0) {
+// ---- epilogue shared by all kernels: Cs holds the 128x128 fp32 tile (pitch CS_PITCH) ----
+// MODE: 0 = no activation, 1 = forward activation, 2 = multiply by the activation derivative at aux_in.
+// FULL: the tile lies entirely inside C and every operand allows vector access: no bounds checks, 8/16-byte
+// accesses only (every tile of the hot shapes except the last row of tiles).
+template <typename T, int ACT, int MODE, bool FULL>
+__device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* Cs, int m0, int n0) {
     const int tid = threadIdx.x;
     const int c4 = (tid & 31) * 4;
     const int n = n0 + c4;
-    const bool vec_c = p.vec_c, vec_aux = p.vec_aux, vec_res = p.vec_res;
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
+        if (FULL) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); bias4[0] = b.x; bias4[1] = b.y; bias4[2] = b.z; bias4[3] = b.w; }
+        else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (n + j < p.N) bias4[j] = p.bias[n + j];
+            for (int j = 0; j < 4; ++j)
+                if (n + j < p.N) bias4[j] = p.bias[n + j];
+        }
     }
     const T* aux_in = reinterpret_cast<const T*>(p.aux_in);
     T* aux_out = reinterpret_cast<T*>(p.aux_out);
@@ -68,52 +73,83 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, const float* Cs, i
     for (int pass = 0; pass < 16; ++pass) {
         const int row = (tid >> 5) + pass * 8;
         const int m = m0 + row;
-        if (m >= p.M || n >= p.N) continue;
+        if (!FULL && (m >= p.M || n >= p.N)) continue;
         const float4 a = *reinterpret_cast<const float4*>(&Cs[row * CS_PITCH + c4]);
         float v[4] = {a.x, a.y, a.z, a.w};
-        const bool full = (n + 3 < p.N);
+        const bool full = FULL || (n + 3 < p.N);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = p.alpha * v[j] + bias4[j];
         if (aux_out) {
             T* q = aux_out + (int64_t)m * p.ld_aux + n;
-            if (full && vec_aux) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
+            if (FULL || (full && p.vec_aux)) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
             else
                 for (int j = 0; j < 4; ++j)
                     if (n + j < p.N) elem<T>::st(q + j, v[j]);
         }
-        if (aux_in) {
+        if (MODE == 2) {
             const T* q = aux_in + (int64_t)m * p.ld_aux + n;
             float u[4] = {0.f, 0.f, 0.f, 0.f};
-            if (full && vec_aux) { float4 t = elem<T>::ld4(q); u[0] = t.x; u[1] = t.y; u[2] = t.z; u[3] = t.w; }
+            if (FULL || (full && p.vec_aux)) { float4 t = elem<T>::ld4(q); u[0] = t.x; u[1] = t.y; u[2] = t.z; u[3] = t.w; }
             else
                 for (int j = 0; j < 4; ++j)
                     if (n + j < p.N) u[j] = elem<T>::ld(q + j);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= act_bwd(p.act, u[j]);
-        } else if (p.act != EAVQA_ACT_NONE) {
+            for (int j = 0; j < 4; ++j) v[j] *= act_bwd(ACT, u[j]);
+        } else if (MODE == 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = act_fwd(p.act, v[j]);
+            for (int j = 0; j < 4; ++j) v[j] = act_fwd(ACT, v[j]);
         }
         if (p.residual) {
             const float* q = p.residual + (int64_t)m * p.ldr + n;
-            if (full && vec_res) { float4 t = *reinterpret_cast<const float4*>(q); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            if (FULL || (full && p.vec_res)) { float4 t = *reinterpret_cast<const float4*>(q); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
             else
                 for (int j = 0; j < 4; ++j)
                     if (n + j < p.N) v[j] += q[j];
         }
         if (p.out_f32) {
             float* q = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
-            if (full && vec_c) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
+            if (FULL || (full && p.vec_c)) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
             else
                 for (int j = 0; j < 4; ++j)
                     if (n + j < p.N) q[j] = v[j];
         } else {
             T* q = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
-            if (full && vec_c) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
+            if (FULL || (full && p.vec_c)) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
             else
                 for (int j = 0; j < 4; ++j)
                     if (n + j < p.N) elem<T>::st(q + j, v[j]);
         }
+    }
+}
+
+template <typename T, int ACT, int MODE>
+__device__ __forceinline__ void epilogue_mode(const GemmParams& p, const float* Cs, int m0, int n0) {
+    const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N) && p.vec_c && (!(p.aux_in || p.aux_out) || p.vec_aux) &&
+                           (!p.residual || p.vec_res) && (!p.bias || p.vec_bias);
+    if (full_tile) epilogue_body<T, ACT, MODE, true>(p, Cs, m0, n0);
+    else epilogue_body<T, ACT, MODE, false>(p, Cs, m0, n0);
+}
+
+// block-uniform dispatch on the (runtime) activation id / mode: each combination gets its own straight-line body
+template <typename T>
+__device__ __forceinline__ void epilogue(const GemmParams& p, const float* Cs, int m0, int n0) {
+    const int mode = p.aux_in ? 2 : (p.act != EAVQA_ACT_NONE ? 1 : 0);
+    if (mode == 0) { epilogue_mode<T, EAVQA_ACT_NONE, 0>(p, Cs, m0, n0); return; }
+    switch (p.act) {
+        case EAVQA_ACT_TANH:
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_TANH, 1>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_TANH, 2>(p, Cs, m0, n0);
+            break;
+        case EAVQA_ACT_RELU:
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_RELU, 1>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_RELU, 2>(p, Cs, m0, n0);
+            break;
+        case EAVQA_ACT_GELU_NEW:
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_GELU_NEW, 1>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_GELU_NEW, 2>(p, Cs, m0, n0);
+            break;
+        case EAVQA_ACT_QUICK_GELU:
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 1>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 2>(p, Cs, m0, n0);
+            break;
+        default:   // aux_in with act == none: derivative 1
+            epilogue_mode<T, EAVQA_ACT_NONE, 0>(p, Cs, m0, n0);
     }
 }
 
@@ -625,6 +661,7 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
     p.vec_c = vec_ok(C, ldc, out_f32 ? 4 : esz);
     p.vec_aux = vec_ok(aux_in ? aux_in : aux_out, ld_aux, esz);
     p.vec_res = vec_ok(residual, ldr, 4);
+    p.vec_bias = (reinterpret_cast<uintptr_t>(bias) % 16) == 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
         if (a_kc && b_kc && (K % FBK) == 0 && !g_disable_fast) return launch_fast(p, s);
