@@ -195,3 +195,63 @@ def test_packed_and_padded_training_steps_agree_fp32():
         assert abs(res[name][0] - res["padded"][0]) <= 1e-6
         for k, g in res["padded"][1].items():
             assert torch.allclose(res[name][1][k], g, atol=1e-6, rtol=1e-5), (name, k)
+
+
+def _oracle_fewshot_generate(sd, cfg, mapper, L, tokens, prefix, mask, n_img, special, max_length, pad, eos):
+    """Few-shot greedy decode restated with the oracle: mapper on every image, insert_prefix_into_input
+    (vct0.py:494-533), then the clipcap greedy loop (clipcap.py:387-471) on the joint embeddings."""
+    wte = sd["transformer.wte.weight"] if cfg["arch"] == "gpt2" else sd["model.decoder.embed_tokens.weight"]
+    B = tokens.shape[0]
+    E = wte.shape[1]
+    pp = oracle.mlp_mapper(prefix.reshape(B * n_img, -1), mapper).reshape(B, n_img, L, E)
+    emb, am = oracle.insert_prefix_into_input(L, n_img - 1, tokens, wte[tokens], pp, mask, special_token_id=special)
+    am = am.float()
+    unfinished = torch.ones(B, 1)
+    toks = None
+    for _ in range(max_length):
+        logits = oracle.lm_logits(sd, cfg, emb, am)
+        nxt = torch.argmax(logits[:, -1, :], -1).unsqueeze(1)
+        emb = torch.cat((emb, wte[nxt]), dim=1)
+        if eos is not None:
+            nxt = nxt * unfinished + pad * (1 - unfinished)
+        toks = nxt if toks is None else torch.cat((toks, nxt), dim=1)
+        am = torch.cat([am, torch.ones(B, 1)], dim=-1)
+        if eos is not None:
+            unfinished = unfinished.mul((nxt != eos).long())
+        if unfinished.max() == 0:
+            break
+    return toks.numpy().astype(int).tolist()
+
+
+@pytest.mark.parametrize("arch,fixture", [("gpt2", "clipcap_gpt2_mlp.npz"), ("opt", "clipcap_opt_mlp.npz")])
+@pytest.mark.parametrize("use_cache", [True, False])
+def test_fewshot_generate_matches_oracle_fp32(arch, fixture, use_cache):
+    """4-shot-style prompt (3 images per row here): sentinel tokens expand into the mapper's prefix rows and the
+    greedy ids equal the oracle's (insert_prefix_into_input + reference greedy loop), float32, exact."""
+    z = load_golden(fixture)
+    model = build_model(z, arch, "mlp", torch.float32).eval()
+    V = int(z["cfg"][0]); D = int(z["cfg"][6]); L = model.prefix_length
+    g = torch.Generator().manual_seed(9)
+    B, n_img, seg = 3, 3, 4
+    special = V - 5
+    T_ = n_img * (1 + seg) + 2
+    tok = torch.randint(3, special - n_img - 1, (B, T_), generator=g)
+    for b in range(B):
+        for i in range(n_img):
+            tok[b, i * (1 + seg) + (b % 2)] = special - i       # sentinel positions differ between rows
+    mask = torch.ones(B, T_, dtype=torch.long)
+    mask[1, -2:] = 0                                              # right padding on one row
+    prefix = torch.randn(B, n_img, D, generator=g)
+    pad = int(z["pad_id"])
+    sd, mapper = sub(z, "lm."), sub(z, "map.")
+    cfg = dict(arch=arch, n_layer=int(z["cfg"][2]), n_head=int(z["cfg"][3]))
+    with torch.no_grad():
+        want = _oracle_fewshot_generate(sd, cfg, mapper, L, tok, prefix, mask, n_img, special, 5, pad, None)
+    got = model.generate_fewshot(tok, prefix, mask, num_shots=n_img - 1, special_token_id=special, max_length=5,
+                                 pad_token_id=pad, eos_token_id=None, use_cache=use_cache)
+    assert got == want
+    bad = tok.clone(); bad[0, 0] = 3; bad[0, 1] = 4     # row 0 loses a sentinel (it sat at index 0)
+    if (bad[0] > special - n_img).sum() != n_img:
+        with pytest.raises(ValueError, match="sentinel"):
+            model.generate_fewshot(bad, prefix, mask, num_shots=n_img - 1, special_token_id=special, max_length=2,
+                                   pad_token_id=pad, eos_token_id=None)
