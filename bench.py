@@ -219,8 +219,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP extension is the only compute path")
-    torch.cuda.set_device(local)
-    device = f"cuda:{local}"
+    # EAVQA_FORCE_DEVICE: rehearse the N > 1 path on a one-GPU box (all ranks on one card, gloo backend)
+    dev_index = int(os.environ.get("EAVQA_FORCE_DEVICE", local))
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
     if _lib.load().eavqa_check_device() != 0:
         raise SystemExit("device is not gfx950")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -322,7 +324,7 @@ def gemm_roofline(stepper, ops):
         # reaches it - the event pairs then bracket pure device time, not host latency between record and launch
         blk_a = torch.randn(8192, 8192, device="cuda").to(torch.bfloat16)
         blk_c = torch.empty(8192, 8192, device="cuda", dtype=torch.bfloat16)
-        for _ in range(48):
+        for _ in range(150):                      # ~0.9 ms each
             real(blk_a, blk_a, out=blk_c)
         stepper.step()
         stepper.flush()

@@ -53,10 +53,17 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
 // MODE: 0 = no activation, 1 = forward activation, 2 = multiply by the activation derivative at aux_in.
 // FULL: the tile lies entirely inside C and every operand allows vector access: no bounds checks, 8/16-byte
 // accesses only (every tile of the hot shapes except the last row of tiles).
-template <typename T, int ACT, int MODE, bool FULL>
+// Geometry G: TPR threads cover one row of the staged tile (4 columns each), RPP rows per pass, NPASS passes, PITCH floats
+// per staged row.
+template <int TPR_, int RPP_, int NPASS_, int PITCH_> struct EpiGeo {
+    static constexpr int TPR = TPR_, RPP = RPP_, NPASS = NPASS_, PITCH = PITCH_;
+};
+using EpiGeo128 = EpiGeo<32, 8, 16, CS_PITCH>;      // 128 x 128 tile, 256 threads
+
+template <typename T, int ACT, int MODE, bool FULL, typename G>
 __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* Cs, int m0, int n0) {
     const int tid = threadIdx.x;
-    const int c4 = (tid & 31) * 4;
+    const int c4 = (tid % G::TPR) * 4;
     const int n = n0 + c4;
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -70,11 +77,11 @@ __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* 
     const T* aux_in = reinterpret_cast<const T*>(p.aux_in);
     T* aux_out = reinterpret_cast<T*>(p.aux_out);
 #pragma unroll 4
-    for (int pass = 0; pass < 16; ++pass) {
-        const int row = (tid >> 5) + pass * 8;
+    for (int pass = 0; pass < G::NPASS; ++pass) {
+        const int row = (tid / G::TPR) + pass * G::RPP;
         const int m = m0 + row;
         if (!FULL && (m >= p.M || n >= p.N)) continue;
-        const float4 a = *reinterpret_cast<const float4*>(&Cs[row * CS_PITCH + c4]);
+        const float4 a = *reinterpret_cast<const float4*>(&Cs[row * G::PITCH + c4]);
         float v[4] = {a.x, a.y, a.z, a.w};
         const bool full = FULL || (n + 3 < p.N);
 #pragma unroll
@@ -122,34 +129,35 @@ __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* 
     }
 }
 
-template <typename T, int ACT, int MODE>
+template <typename T, int ACT, int MODE, typename G>
 __device__ __forceinline__ void epilogue_mode(const GemmParams& p, const float* Cs, int m0, int n0) {
-    const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N) && p.vec_c && (!(p.aux_in || p.aux_out) || p.vec_aux) &&
+    constexpr int ROWS = G::RPP * G::NPASS, COLS = G::TPR * 4;
+    const bool full_tile = (m0 + ROWS <= p.M) && (n0 + COLS <= p.N) && p.vec_c && (!(p.aux_in || p.aux_out) || p.vec_aux) &&
                            (!p.residual || p.vec_res) && (!p.bias || p.vec_bias);
-    if (full_tile) epilogue_body<T, ACT, MODE, true>(p, Cs, m0, n0);
-    else epilogue_body<T, ACT, MODE, false>(p, Cs, m0, n0);
+    if (full_tile) epilogue_body<T, ACT, MODE, true, G>(p, Cs, m0, n0);
+    else epilogue_body<T, ACT, MODE, false, G>(p, Cs, m0, n0);
 }
 
 // block-uniform dispatch on the (runtime) activation id / mode: each combination gets its own straight-line body
-template <typename T>
+template <typename T, typename G = EpiGeo128>
 __device__ __forceinline__ void epilogue(const GemmParams& p, const float* Cs, int m0, int n0) {
     const int mode = p.aux_in ? 2 : (p.act != EAVQA_ACT_NONE ? 1 : 0);
-    if (mode == 0) { epilogue_mode<T, EAVQA_ACT_NONE, 0>(p, Cs, m0, n0); return; }
+    if (mode == 0) { epilogue_mode<T, EAVQA_ACT_NONE, 0, G>(p, Cs, m0, n0); return; }
     switch (p.act) {
         case EAVQA_ACT_TANH:
-            if (mode == 1) epilogue_mode<T, EAVQA_ACT_TANH, 1>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_TANH, 2>(p, Cs, m0, n0);
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_TANH, 1, G>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_TANH, 2, G>(p, Cs, m0, n0);
             break;
         case EAVQA_ACT_RELU:
-            if (mode == 1) epilogue_mode<T, EAVQA_ACT_RELU, 1>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_RELU, 2>(p, Cs, m0, n0);
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_RELU, 1, G>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_RELU, 2, G>(p, Cs, m0, n0);
             break;
         case EAVQA_ACT_GELU_NEW:
-            if (mode == 1) epilogue_mode<T, EAVQA_ACT_GELU_NEW, 1>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_GELU_NEW, 2>(p, Cs, m0, n0);
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_GELU_NEW, 1, G>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_GELU_NEW, 2, G>(p, Cs, m0, n0);
             break;
         case EAVQA_ACT_QUICK_GELU:
-            if (mode == 1) epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 1>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 2>(p, Cs, m0, n0);
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 1, G>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 2, G>(p, Cs, m0, n0);
             break;
         default:   // aux_in with act == none: derivative 1
-            epilogue_mode<T, EAVQA_ACT_NONE, 0>(p, Cs, m0, n0);
+            epilogue_mode<T, EAVQA_ACT_NONE, 0, G>(p, Cs, m0, n0);
     }
 }
 
@@ -343,7 +351,7 @@ __device__ __forceinline__ bool fast_tile(const GemmParams& p, int gx, int gy, i
             else __builtin_amdgcn_s_waitcnt(0x0F70);                 /* vmcnt(0) */                     \
             __builtin_amdgcn_s_barrier();                                                             \
             }                                                                                         \
-            if (ABL < 1 && (t) + 4 < nk) issue((t) + 4);                                              \
+            if ((ABL < 1 || ABL == 4) && (t) + 4 < nk) issue((t) + 4);                                \
             if (ABL < 2) {                                                                            \
             const char* st = smem + (((t) + 1) & (FSTAGES - 1)) * FSTAGE;                             \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
@@ -354,13 +362,15 @@ __device__ __forceinline__ bool fast_tile(const GemmParams& p, int gx, int gy, i
             _Pragma("unroll") for (int i = 0; i < 4; ++i) { fa[(P) ^ 1][i] = fa[P][i]; fb[(P) ^ 1][i] = fb[P][i]; } \
             }                                                                                         \
         }                                                                                             \
+        if (ABL != 4) {                                                                               \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                 \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[P][i], fb[P][j], acc[i][j], 0, 0, 0); \
+        }                                                                                             \
     }
 
 // ABL (timing experiments only, results are wrong for ABL != 0): 1 = no DMA in the main loop, 2 = also no
-// fragment reads, 3 = also no barrier / waits (bare MFMA loop)
+// fragment reads, 3 = also no barrier / waits (bare MFMA loop), 4 = DMA + waits + barriers only (no reads, no MFMA)
 template <int ABL>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, int gx, int gy, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -455,17 +465,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
 typedef void (*fast_kernel_t)(GemmParams, int, int, int);
 
 int launch_fast(const GemmParams& p, hipStream_t stream) {
-    static const fast_kernel_t kernels[4] = {gemm_bf16_fast_kernel<0>, gemm_bf16_fast_kernel<1>, gemm_bf16_fast_kernel<2>,
-                                             gemm_bf16_fast_kernel<3>};
+    static const fast_kernel_t kernels[5] = {gemm_bf16_fast_kernel<0>, gemm_bf16_fast_kernel<1>, gemm_bf16_fast_kernel<2>,
+                                             gemm_bf16_fast_kernel<3>, gemm_bf16_fast_kernel<4>};
     static bool configured = false;
     if (!configured) {
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 5; ++i)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     CS_BYTES) != hipSuccess)
                 return EAVQA_E_LAUNCH;
         configured = true;
     }
-    const fast_kernel_t kernel = kernels[g_ablate & 3];
+    const fast_kernel_t kernel = kernels[g_ablate <= 4 ? g_ablate : 0];
     // XCD grid gx x gy = 8 minimising the panels one XCD touches (rows + cols of its rectangle)
     int best_gx = 8, best_cost = 1 << 30;
     const int cand[4] = {8, 4, 2, 1};
@@ -479,6 +489,157 @@ int launch_fast(const GemmParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(kernel, dim3(per_xcd * 8), dim3(256), CS_BYTES, stream, p, gx, gy, g_stagger);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
+}
+
+
+// ====================================================== bf16 big tiles ===
+// 256 x 256 output tile per 1024-thread workgroup (16 waves as 4 x 4, 64 x 64 each, four waves per SIMD) for GEMMs
+// with enough columns to give most CUs a tile (N >= 3840 on the hot path: QKV, FFN up, lm_head; the CLIP tower and
+// the few-shot prefill).  Why: with 128 x 128 tiles every FLOP costs 1/64 B of L2 -> LDS traffic and the LDS-DMA path
+// of a CU saturates near 30 B/clk, well before the matrix pipe; a 256 x 256 tile halves that (1/128 B per FLOP) and
+// four waves per SIMD hide the fragment-read latency without a second register set.
+//   * BK = 64: LDS rows are full 128-byte lines (every DMA instruction moves 8 whole rows), XOR swizzle chunk ^= row & 7;
+//   * 2 stages x 64 KiB; tile t+1 is fetched (LDS-DMA) while tile t multiplies (32 MFMAs per wave ~ 2048 cycles per
+//     SIMD, which covers an L2 round trip); one s_barrier per K-tile;
+//   * the C tile leaves through LDS one 64-row slab at a time (the accumulators of one wave row).
+constexpr int GBM = 256, GBN = 256, GBK = 64;
+constexpr int GOPER = GBM * GBK * 2;               // 32 KiB per operand per stage
+constexpr int GSTAGE = 2 * GOPER;                  // 64 KiB
+constexpr int GCS_PITCH = GBN + 4;                 // floats per staged C row
+constexpr int GLDS_BYTES = 2 * GSTAGE;             // 128 KiB (the 64 x 260 fp32 slab reuses it)
+using EpiGeo256 = EpiGeo<64, 16, 4, GCS_PITCH>;    // 64 x 256 slab, 1024 threads
+
+__device__ __forceinline__ bool big_tile(const GemmParams& p, int gx, int gy, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int xi = xcd % gx, yi = xcd / gx;
+    const int qm = tiles_m / gx, rm = tiles_m % gx, qn = tiles_n / gy, rn = tiles_n % gy;
+    const int m_begin = xi * qm + min(xi, rm), m_cnt = qm + (xi < rm ? 1 : 0);
+    const int n_begin = yi * qn + min(yi, rn), n_cnt = qn + (yi < rn ? 1 : 0);
+    if (m_cnt == 0 || local >= m_cnt * n_cnt) return false;
+    tm = m_begin + local % m_cnt;
+    tn = n_begin + local / m_cnt;
+    return true;
+}
+
+__global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tm, tn;
+    if (!big_tile(p, gx, gy, tiles_m, tiles_n, tm, tn)) return;
+    const int m0 = tm * GBM, n0 = tn * GBN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+
+    // DMA sources: chunk c = tid + 1024 i of the [256 rows][8 chunks] image (row = c >> 3, physical chunk c & 7)
+    const bf16_t* asrc[2];
+    const bf16_t* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 1024 * i;
+        const int row = c >> 3, pc = c & 7;
+        const int kc = pc ^ (row & 7);
+        asrc[i] = A + (int64_t)min(m0 + row, p.M - 1) * p.lda + kc * 8;
+        bsrc[i] = B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + kc * 8;
+    }
+    const int dma_off = wave * 1024;
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 1) * GSTAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * GBK),
+                                             (__attribute__((address_space(3))) void*)(st + dma_off + i * 16384), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * GBK),
+                                             (__attribute__((address_space(3))) void*)(st + GOPER + dma_off + i * 16384), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / GBK;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int arow = wm * 64 + frow, brow = wn * 64 + frow;     // + 16 i ; row & 7 == frow & 7 for every fragment
+    issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0): this wave's share of tile kt has landed
+        __builtin_amdgcn_s_barrier();              // ... and everybody's; all reads of the other stage are done
+        if (kt + 1 < nk) issue(kt + 1);
+        const char* st = smem + (kt & 1) * GSTAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[4], bfr[4];
+            const int sw = ((s * 4 + fk) ^ (frow & 7)) << 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + (arow + 16 * i) * 128 + sw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + GOPER + (brow + 16 * j) * 128 + sw);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    float* Cs = reinterpret_cast<float*>(smem);
+    for (int slab = 0; slab < 4; ++slab) {
+        if (wm == slab) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = i * 16 + (lane >> 4) * 4 + r;
+                        const int col = wn * 64 + j * 16 + (lane & 15);
+                        Cs[row * GCS_PITCH + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        epilogue<bf16_t, EpiGeo256>(p, Cs, m0 + slab * 64, n0);
+        __syncthreads();
+    }
+}
+
+int launch_big(const GemmParams& p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GLDS_BYTES) != hipSuccess)
+            return EAVQA_E_LAUNCH;
+        configured = true;
+    }
+    const int tiles_m = (p.M + GBM - 1) / GBM, tiles_n = (p.N + GBN - 1) / GBN;
+    int best_gx = 8, best_cost = 1 << 30;
+    const int cand[4] = {8, 4, 2, 1};
+    for (int c = 0; c < 4; ++c) {
+        const int gx = cand[c], gy = 8 / gx;
+        const int cost = (tiles_m + gx - 1) / gx + (tiles_n + gy - 1) / gy;
+        if (cost < best_cost) { best_cost = cost; best_gx = gx; }
+    }
+    const int gx = best_gx, gy = 8 / gx;
+    const int per_xcd = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
+    hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3(per_xcd * 8), dim3(1024), GLDS_BYTES, stream, p, gx, gy, tiles_m, tiles_n);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+// 0 = choose by shape, 1 = never the big kernel, 2 = always (when K % 64 == 0)
+int g_big_mode = 0;
+
+bool use_big(const GemmParams& p) {
+    if (p.K % GBK) return false;
+    if (g_big_mode == 1) return false;
+    if (g_big_mode == 2) return true;
+    const int tiles = ((p.M + GBM - 1) / GBM) * ((p.N + GBN - 1) / GBN);
+    return tiles >= 144;     // measured crossover on MI355X: below ~140 tiles the 128 x 128 kernel (more CUs busy) wins
 }
 
 // ================================================================ f32 ===
@@ -626,7 +787,7 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 extern "C" void eavqa_debug_disable_fast_gemm(int disable) { g_disable_fast = disable != 0; }
-extern "C" void eavqa_debug_gemm_stagger(int units) { g_stagger = units & 0xff; g_ablate = (units >> 8) & 3; }
+extern "C" void eavqa_debug_gemm_stagger(int units) { g_stagger = units & 0xff; g_ablate = (units >> 8) & 7; g_big_mode = (units >> 16) & 3; }
 
 extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                           const void* A, int64_t lda, const void* B, int64_t ldb,
@@ -664,6 +825,7 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
     p.vec_bias = (reinterpret_cast<uintptr_t>(bias) % 16) == 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
+        if (a_kc && b_kc && !g_disable_fast && use_big(p)) return launch_big(p, s);
         if (a_kc && b_kc && (K % FBK) == 0 && !g_disable_fast) return launch_fast(p, s);
         if (a_kc && b_kc) return launch(gemm_bf16_kernel<true, true>, p, s);
         if (a_kc && !b_kc) return launch(gemm_bf16_kernel<true, false>, p, s);

@@ -81,8 +81,9 @@ int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
 /* Test hook (host, not thread-safe): non-zero routes bf16 k-contiguous GEMMs with K % 32 == 0 through the
  * general register-staged kernel instead of the LDS-DMA fast path, so that both are covered by parity tests. */
 void eavqa_debug_disable_fast_gemm(int disable);
-/* Experiment knob (host): start-up delay, in units of 8 x 64 cycles, of every other co-resident workgroup of the
- * fast GEMM kernel (0 = none). */
+/* Experiment knob (host), bit fields of `units`: [7:0] start-up delay (x 8 x 64 cycles) of every other co-resident
+ * workgroup of the 128 x 128 LDS-DMA kernel; [9:8] timing-only ablation variant (results wrong when non-zero);
+ * [17:16] tile choice: 0 by shape, 1 never the 256 x 256 kernel, 2 always the 256 x 256 kernel (K % 64 == 0). */
 void eavqa_debug_gemm_stagger(int units);
 /* Test hook (host): non-zero keeps bf16 attention on the vector-ALU kernels instead of the matrix-core ones. */
 void eavqa_debug_attention_valu(int force);

@@ -43,19 +43,23 @@ ACTS = {
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=["fast", "general"])
+@pytest.fixture(params=["fast", "general", "big"])
 def gemm_path(request):
-    """bf16 k-contiguous GEMMs with K % 32 == 0 take the LDS-DMA fast kernel; run every case through both."""
+    """bf16 k-contiguous GEMMs take the 128x128 LDS-DMA kernel (K % 32 == 0) or the 256x256 one (K % 64 == 0, chosen by
+    shape); run every case through the general kernel, the 128x128 kernel and (forced) the 256x256 kernel."""
     from eavqa_amd import _lib
-    _lib.load().eavqa_debug_disable_fast_gemm(int(request.param == "general"))
+    lib = _lib.load()
+    lib.eavqa_debug_disable_fast_gemm(int(request.param == "general"))
+    lib.eavqa_debug_gemm_stagger({"fast": 1, "general": 1, "big": 2}[request.param] << 16)
     yield request.param
-    _lib.load().eavqa_debug_disable_fast_gemm(0)
+    lib.eavqa_debug_disable_fast_gemm(0)
+    lib.eavqa_debug_gemm_stagger(0)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("a_kc,b_kc", [(True, True), (True, False), (False, True), (False, False)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 72), (1, 8, 8), (64, 520, 1032), (300, 50257 // 64, 128),
-                                   (2688, 1280, 1280), (130, 3000, 32), (257, 129, 96)])
+                                   (2688, 1280, 1280), (130, 3000, 32), (257, 129, 96), (300, 700, 192), (1943, 5120, 128)])
 def test_gemm_layouts_and_edges(ops, gemm_path, dtype, a_kc, b_kc, M, N, K):
     vec = 8 if dtype == torch.bfloat16 else 4
     if (not a_kc and M % vec) or (not b_kc and N % vec):

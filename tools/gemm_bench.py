@@ -31,10 +31,11 @@ def main():
     ap.add_argument("--epilogue", action="store_true", help="bias + gelu_new + aux_out like fc1")
     ap.add_argument("--stagger", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation variant of the fast kernel (wrong results)")
+    ap.add_argument("--big", type=int, default=0, help="0 auto, 1 never 256x256, 2 always 256x256")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
     _lib.load().eavqa_debug_disable_fast_gemm(int(args.general))
-    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8))
+    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8) | (args.big << 16))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
     for M, N, K, what in SHAPES:
