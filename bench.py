@@ -265,9 +265,10 @@ def main():
     value = world * B * args.steps / dt
 
     roof = None
-    if not args.no_roofline and rank == 0:
-        roof = gemm_roofline(stepper, ops)
-        log(f"roofline pass done: {roof}")
+    if not args.no_roofline:
+        roof = gemm_roofline(stepper, ops)      # every rank runs it (the step contains the all-reduce); rank 0 reports
+        if rank == 0:
+            log(f"roofline pass done: {roof}")
     extra = None
     if rank == 0 and world == 1 and not args.no_fewshot:
         del stepper, vit, model, opt          # free the training workload's HBM first

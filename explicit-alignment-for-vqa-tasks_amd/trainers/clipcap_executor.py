@@ -24,7 +24,7 @@ from .. import ops
 from ..models.clipcap import ClipCaptionModel, ClipCaptionPrefix  # noqa: F401  (looked up by name, :52)
 from ..utils.attrdict import AttrDict
 from .data_parallel import GradSync
-from .optim import ConstantScheduleWithWarmup, FusedAdamW
+from .optim import ConstantScheduleWithWarmup, CosineAnnealing, FusedAdamW, LinearScheduleWithWarmup
 
 
 class ClipCapExecutor:
@@ -53,15 +53,21 @@ class ClipCapExecutor:
     def log(self, name, value, **kwargs):
         self.logged[name] = value
 
-    def configure_optimizers(self):
-        """clipcap_exector.py:58-130 ("linear"/"cosine" schedules are not on the benchmarked path)."""
+    def configure_optimizers(self, num_training_steps: Optional[int] = None):
+        """clipcap_exector.py:58-130: AdamW (torch defaults) + "linear" | "cosine" | constant-with-warmup schedule.
+        ``num_training_steps`` stands in for ``trainer.estimated_stepping_batches`` (:90)."""
         tr = self.config.train
         self.optimizer = FusedAdamW(self.model.clip_project.flat, lr=tr.lr)
         sched = tr.get("scheduler", "none")
-        if sched not in ("none", None, "constant"):
-            raise NotImplementedError(f"scheduler {sched!r}: only the reference default (constant with warmup) is built")
         warm = tr.get("additional", {}).get("warmup_steps", 0)
-        self.scheduler = ConstantScheduleWithWarmup(self.optimizer, warm)
+        if sched == "linear":
+            if num_training_steps is None:
+                raise ValueError("the linear schedule needs num_training_steps (trainer.estimated_stepping_batches)")
+            self.scheduler = LinearScheduleWithWarmup(self.optimizer, warm, num_training_steps)
+        elif sched == "cosine":
+            self.scheduler = CosineAnnealing(self.optimizer, tr.epochs, eta_min=1e-5)
+        else:
+            self.scheduler = ConstantScheduleWithWarmup(self.optimizer, warm)
         return {"optimizer": self.optimizer, "lr_scheduler": {"scheduler": self.scheduler, "interval": "step", "frequency": 1}}
 
     def _clip_embeddings(self, batch) -> torch.Tensor:

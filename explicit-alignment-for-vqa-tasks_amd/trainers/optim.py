@@ -63,3 +63,32 @@ class ConstantScheduleWithWarmup:
 
     def get_last_lr(self):
         return [g["lr"] for g in self.opt.param_groups]
+
+
+class LinearScheduleWithWarmup(ConstantScheduleWithWarmup):
+    """``get_linear_schedule_with_warmup`` (``"scheduler": "linear"``, clipcap_exector.py:83-92): linear warm-up to lr,
+    then linear decay to 0 at ``num_training_steps``."""
+
+    def __init__(self, optimizer: FusedAdamW, num_warmup_steps: int, num_training_steps: int):
+        self.total = max(1, num_training_steps)
+        super().__init__(optimizer, num_warmup_steps)
+
+    def _factor(self) -> float:
+        if self.n < self.warmup:
+            return float(self.n) / float(max(1, self.warmup))
+        return max(0.0, float(self.total - self.n) / float(max(1, self.total - self.warmup)))
+
+
+class CosineAnnealing(ConstantScheduleWithWarmup):
+    """``optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=epochs, eta_min=1e-5)`` (``"scheduler": "cosine"``,
+    clipcap_exector.py:93-101), closed form."""
+
+    def __init__(self, optimizer: FusedAdamW, t_max: int, eta_min: float = 1e-5):
+        import math
+        self._math, self.t_max, self.eta_min = math, max(1, t_max), eta_min
+        super().__init__(optimizer, 0)
+
+    def _apply(self) -> None:
+        for g in self.opt.param_groups:
+            base = g["initial_lr"]
+            g["lr"] = self.eta_min + (base - self.eta_min) * (1 + self._math.cos(self._math.pi * self.n / self.t_max)) / 2
