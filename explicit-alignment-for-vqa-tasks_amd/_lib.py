@@ -48,7 +48,16 @@ SIGNATURES = {
     "eavqa_vit_assemble": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, i64, ptr],
     "eavqa_cast_rows": [i32, i32, i64, ptr, i64, ptr, i64, ptr],
 }
-_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_debug_disable_fast_gemm": None, "eavqa_debug_gemm_stagger": None, "eavqa_debug_attention_valu": None}
+class LMLayer(C.Structure):
+    """``eavqa_lm_layer_t``."""
+    _fields_ = [(n, C.c_void_p) for n in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b", "w_fc1", "b_fc1",
+                                          "w_fc2", "b_fc2", "k_cache", "v_cache")]
+
+
+SIGNATURES["eavqa_lm_block_workspace_bytes"] = [i32, i32, i32, i32]
+SIGNATURES["eavqa_lm_block_forward"] = [i32, i32, C.POINTER(LMLayer), i32, i32, i32, i32, f32, i32, i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr]
+
+_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_debug_disable_fast_gemm": None, "eavqa_debug_gemm_stagger": None, "eavqa_debug_attention_valu": None, "eavqa_lm_block_workspace_bytes": C.c_int64}
 
 _lib = None
 

@@ -21,7 +21,7 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libeavqa_hip.so")
 
 HIP_SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "seq.hip", "loss.hip", "optim.hip"]
-CPP_SOURCES = ["api.cpp"]
+CPP_SOURCES = ["api.cpp", "lm_block.cpp"]
 ARCH = "gfx950"
 
 

@@ -642,6 +642,89 @@ bool use_big(const GemmParams& p) {
     return tiles >= 144;     // measured crossover on MI355X: below ~140 tiles the 128 x 128 kernel (more CUs busy) wins
 }
 
+
+// ======================================================= bf16 skinny M ===
+// M <= 64 rows (a decode step: M = batch; the MLP mapper at batch 64): the GEMM is a weight-streaming problem, HBM
+// bound on B.  Each workgroup owns 16 output columns and its 8 waves split K; a wave loads its B fragment (16 rows x
+// 32 k, 16 B per lane) and the matching A fragments straight into VGPRs (no LDS round trip: nothing is shared between
+// waves), eight K-steps unrolled so that >= 16 loads are in flight per wave, one MFMA per A fragment and step.
+// The 8 partial tiles are summed through LDS and a scalar epilogue (same semantics as the tiled kernels) writes the
+// 16 x M results.  Algorithmic bytes: N*K*2 (weights) once; A (<= 64 x K) is re-read from L2 by every workgroup.
+template <int MF>
+__global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(GemmParams p) {
+    __shared__ float red[8][64][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+    const int nsteps = p.K >> 5;
+    const int per_wave = (nsteps + 7) >> 3;
+    const int s_begin = wave * per_wave, s_end = min(nsteps, s_begin + per_wave);
+    const bf16_t* bp = B + (int64_t)min(n0 + x, p.N - 1) * p.ldb + 8 * g;
+    const bf16_t* ap[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) ap[f] = A + (int64_t)min(16 * f + x, p.M - 1) * p.lda + 8 * g;
+    f32x4 acc[MF];
+#pragma unroll
+    for (int f = 0; f < MF; ++f) acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int s = s_begin;
+    for (; s + 8 <= s_end; s += 8) {
+        bf16x8 b[8], a[8][MF];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            b[u] = *reinterpret_cast<const bf16x8*>(bp + (s + u) * 32);
+#pragma unroll
+            for (int f = 0; f < MF; ++f) a[u][f] = *reinterpret_cast<const bf16x8*>(ap[f] + (s + u) * 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int f = 0; f < MF; ++f) acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][f], b[u], acc[f], 0, 0, 0);
+    }
+    for (; s < s_end; ++s) {
+        const bf16x8 b = *reinterpret_cast<const bf16x8*>(bp + s * 32);
+#pragma unroll
+        for (int f = 0; f < MF; ++f) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(ap[f] + s * 32);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[f], 0, 0, 0);
+        }
+    }
+    // C fragment: row m = 16 f + 4 g + r, column n = n0 + x
+#pragma unroll
+    for (int f = 0; f < MF; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][16 * f + 4 * g + r][x] = acc[f][r];
+    __syncthreads();
+    for (int e = tid; e < MF * 16 * 16; e += 512) {
+        const int m = e >> 4, c = e & 15, n = n0 + c;
+        if (m >= p.M || n >= p.N) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += red[w][m][c];
+        v = p.alpha * v + (p.bias ? p.bias[n] : 0.f);
+        const int64_t ia = (int64_t)m * p.ld_aux + n;
+        if (p.aux_out) elem<bf16_t>::st(reinterpret_cast<bf16_t*>(p.aux_out) + ia, v);
+        if (p.aux_in) v *= act_bwd(p.act, elem<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p.aux_in) + ia));
+        else v = act_fwd(p.act, v);
+        if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
+        if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = v;
+        else elem<bf16_t>::st(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n, v);
+    }
+}
+
+int launch_skinny(const GemmParams& p, hipStream_t stream) {
+    const int blocks = (p.N + 15) / 16;
+    const int mf = (p.M + 15) / 16;
+    if (mf == 1) hipLaunchKernelGGL(gemm_bf16_skinny_kernel<1>, dim3(blocks), dim3(512), 0, stream, p);
+    else if (mf == 2) hipLaunchKernelGGL(gemm_bf16_skinny_kernel<2>, dim3(blocks), dim3(512), 0, stream, p);
+    else if (mf == 3) hipLaunchKernelGGL(gemm_bf16_skinny_kernel<3>, dim3(blocks), dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_bf16_skinny_kernel<4>, dim3(blocks), dim3(512), 0, stream, p);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
 // ================================================================ f32 ===
 constexpr int BK32 = 16;
 constexpr int PITCH32 = 17;                                  // floats per staged row
@@ -825,6 +908,7 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
     p.vec_bias = (reinterpret_cast<uintptr_t>(bias) % 16) == 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
+        if (a_kc && b_kc && !g_disable_fast && M <= 64 && (K % 32) == 0 && N >= 64) return launch_skinny(p, s);
         if (a_kc && b_kc && !g_disable_fast && use_big(p)) return launch_big(p, s);
         if (a_kc && b_kc && (K % FBK) == 0 && !g_disable_fast) return launch_fast(p, s);
         if (a_kc && b_kc) return launch(gemm_bf16_kernel<true, true>, p, s);

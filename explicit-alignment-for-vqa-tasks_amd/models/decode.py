@@ -15,7 +15,7 @@ from typing import List, Optional
 
 import torch
 
-from .. import ops
+from .. import _lib, ops
 from .lm import FrozenCausalLM
 
 Tensor = torch.Tensor
@@ -32,7 +32,7 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
     unfinished = torch.ones(B, dtype=torch.int32, device=dev)
     produced = 0
     if use_cache:
-        cache = _KVCache(lm, B, S_max)
+        cache = _KVCache(lm, B, S_max, B * S0)
         logits = _prefill(lm, cache, prefix_rows, src[:, :S0].contiguous(), pos[:, :S0].contiguous(), mask, B, S0, S_max)
     for t in range(max_length):
         if not use_cache:
@@ -50,29 +50,30 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
 
 
 class _KVCache:
-    def __init__(self, lm: FrozenCausalLM, B: int, S_max: int):
-        E = lm.cfg.n_embd
+    """Per-layer K/V ``[B, S_max, E]`` plus the host-side layer table and scratch for ``eavqa_lm_block_forward``."""
+
+    def __init__(self, lm: FrozenCausalLM, B: int, S_max: int, max_rows: int):
+        E, F = lm.cfg.n_embd, lm.cfg.ffn
         self.k = [torch.empty((B * S_max, E), device=lm.device, dtype=lm.dtype) for _ in lm.layers]
         self.v = [torch.empty((B * S_max, E), device=lm.device, dtype=lm.dtype) for _ in lm.layers]
+        self.table = (_lib.LMLayer * len(lm.layers))()
+        for i, L in enumerate(lm.layers):
+            t = self.table[i]
+            for name in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2"):
+                setattr(t, name, getattr(L, name).data_ptr())
+            t.k_cache, t.v_cache = self.k[i].data_ptr(), self.v[i].data_ptr()
+        lib = _lib.load()
+        self.ws_bytes = int(lib.eavqa_lm_block_workspace_bytes(ops.dtype_id(lm.dtype), max_rows, E, F))
+        self.ws = torch.empty(self.ws_bytes, device=lm.device, dtype=torch.uint8)
 
 
 def _block(lm: FrozenCausalLM, cache: _KVCache, x: Tensor, mask: Tensor, B: int, Sq: int, row0: int, S_max: int) -> Tensor:
-    """All decoder layers for ``Sq`` new positions per row starting at sequence index ``row0``;
-    K/V of the new positions are appended to the cache and attention runs against rows [0, row0+Sq)."""
-    c, T = lm.cfg, lm.dtype
-    E, H, hd = c.n_embd, c.n_head, c.head_dim
-    Sk = row0 + Sq
-    for li, L in enumerate(lm.layers):
-        a = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T)
-        qkv = ops.gemm(a, L.w_qkv, bias=L.b_qkv)
-        ops.copy_rows(qkv[:, E:2 * E], cache.k[li], B, Sq, E, Sq, S_max, row0)
-        ops.copy_rows(qkv[:, 2 * E:], cache.v[li], B, Sq, E, Sq, S_max, row0)
-        ctx = ops.attention_fwd(qkv[:, :E], cache.k[li], cache.v[li], B, H, Sq, Sk, hd, key_mask=mask, causal=True,
-                                scale=hd ** -0.5, kv_batch_rows=S_max, ld_mask=mask.stride(0))
-        x1 = ops.gemm(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True)
-        a2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T)
-        f = ops.gemm(a2, L.w_fc1, bias=L.b_fc1, act=c.act)
-        x = ops.gemm(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True)
+    """All decoder layers for ``Sq`` new positions per row starting at sequence index ``row0`` (one C call): K/V of the
+    new positions are appended to the cache and attention runs against rows [0, row0+Sq).  ``x`` is updated in place."""
+    c = lm.cfg
+    _lib.call("eavqa_lm_block_forward", ops.dtype_id(lm.dtype), len(lm.layers), cache.table, c.n_embd, c.n_head, c.ffn,
+              _lib.ACT[c.act], float(c.eps), B, Sq, row0, S_max, x.data_ptr(), mask.data_ptr(), mask.stride(0), cache.ws.data_ptr(),
+              cache.ws_bytes, ops._stream())
     return x
 
 

@@ -234,6 +234,28 @@ int eavqa_patchify(int dtype, int B, int img, int ps, const float* pixels, void*
 int eavqa_vit_assemble(int dtype, int B, int n_patch, int W, const void* patch_embed, int64_t ldpe,
                        const float* cls, const float* pos, float* x, int64_t ldx, void* stream);
 
+/* ------------------------------------------------- decoder-layer driver ---
+ * All `n_layer` pre-LN decoder layers (HF:gpt2 :246-309 / HF:opt :184-254) for Sq NEW positions per sample in one
+ * call, with a per-layer KV cache [B, S_max, E]: K/V of the new positions are appended at sequence index row0 and
+ * attention (causal, key mask row b at key_mask + b*ld_mask) runs against positions [0, row0+Sq).  Prefill: row0 = 0,
+ * Sq = prompt length; decode step t: row0 = prompt + t, Sq = 1 (the reference re-runs the whole sequence instead,
+ * clipcap.py:414-419).  x: float32 residual stream [B*Sq, E], updated in place.  Weights are in the packed layouts of
+ * eavqa_gemm's b_kc form ([out, in]); `layers` is a HOST array.  workspace: device scratch of at least
+ * eavqa_lm_block_workspace_bytes(dtype, B*Sq, E, F) bytes.  Enqueue-only. */
+typedef struct {
+    const float* ln1_g; const float* ln1_b;
+    const void* w_qkv; const float* b_qkv;      /* [3E, E], [3E] */
+    const void* w_o; const float* b_o;          /* [E, E], [E] */
+    const float* ln2_g; const float* ln2_b;
+    const void* w_fc1; const float* b_fc1;      /* [F, E], [F] */
+    const void* w_fc2; const float* b_fc2;      /* [E, F], [E] */
+    void* k_cache; void* v_cache;               /* [B, S_max, E] in `dtype` */
+} eavqa_lm_layer_t;
+int64_t eavqa_lm_block_workspace_bytes(int dtype, int rows, int E, int F);
+int eavqa_lm_block_forward(int dtype, int n_layer, const eavqa_lm_layer_t* layers, int E, int H, int F, int act, float eps,
+                           int B, int Sq, int row0, int S_max, float* x, const int32_t* key_mask, int64_t ld_mask,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* float32 -> `dtype` elementwise copy with row strides (casts the residual stream / pooled rows). */
 int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream);
 

@@ -129,27 +129,3 @@ def test_generative_step_contract(dtype):
     assert [p["question_id"] for p in out["predictions"]] == [11, 12, 13, 14]
     assert len(out["outputs"]) == 4 and all(1 <= len(o) <= 4 for o in out["outputs"])
     assert all(isinstance(p["answer"], str) for p in out["predictions"])
-
-
-def test_schedules():
-    from eavqa_amd.trainers.optim import ConstantScheduleWithWarmup, CosineAnnealing, LinearScheduleWithWarmup
-
-    class Opt:
-        param_groups = [dict(lr=1.0, initial_lr=1.0)]
-    s = ConstantScheduleWithWarmup(Opt(), 4)
-    seq = []
-    for _ in range(6):
-        seq.append(s.get_last_lr()[0]); s.step()
-    assert seq == [0.0, 0.25, 0.5, 0.75, 1.0, 1.0]
-    ref = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
-    from torch.optim.lr_scheduler import CosineAnnealingLR, LambdaLR
-    cos_ref = CosineAnnealingLR(ref, 10, eta_min=1e-5)
-    c = CosineAnnealing(Opt(), 10)
-    for _ in range(7):
-        assert abs(c.get_last_lr()[0] - cos_ref.get_last_lr()[0]) < 1e-6
-        ref.step(); cos_ref.step(); c.step()
-    lin = LinearScheduleWithWarmup(Opt(), 2, 10)
-    vals = []
-    for _ in range(11):
-        vals.append(round(lin.get_last_lr()[0], 4)); lin.step()
-    assert vals == [0.0, 0.5, 1.0, 0.875, 0.75, 0.625, 0.5, 0.375, 0.25, 0.125, 0.0]

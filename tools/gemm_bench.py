@@ -15,6 +15,8 @@ import torch
 from eavqa_amd import _lib, ops
 
 SHAPES = [  # (M, N, K, what)
+    (32, 7680, 2560, "decode qkv"), (32, 2560, 2560, "decode proj"), (32, 10240, 2560, "decode fc1"), (32, 2560, 10240, "decode fc2"),
+    (32, 50272, 2560, "decode lm_head"), (64, 12800, 6400, "mlp fc2 fwd"),
     (2688, 1280, 32, "fixed K=32"), (2688, 1280, 320, "fixed K=320"), (1943, 1280, 1280, "packed proj"), (1943, 3840, 1280, "packed qkv"),
     (1943, 5120, 1280, "packed fc1"), (1943, 1280, 5120, "packed fc2"),
     (2688, 3840, 1280, "qkv fwd"), (2688, 1280, 1280, "proj fwd / dctx"), (2688, 5120, 1280, "fc1 fwd / du"),
