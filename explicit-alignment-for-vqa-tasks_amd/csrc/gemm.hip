@@ -22,6 +22,7 @@ namespace {
 bool g_disable_fast = false;   // test hook: exercise the general kernel on fast-path shapes
 int g_stagger = 0;             // experiment knob: s_sleep units for odd co-resident blocks of the fast kernel
 int g_ablate = 0;              // experiment knob: ablation variant of the fast kernel (timing only)
+int g_deep = 0;                // 2 = force the 8-stage ring (experiment)
 
 struct GemmParams {
     const void* A; const void* B; void* C;
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
 //   * the LDS footprint (ring 64 KiB, C staging 66 KiB) lets two workgroups share a CU;
 //   * block -> tile map: each XCD (blockIdx % 8) owns a rectangle of the tile grid so that the
 //     A / B panels it re-reads stay in its own 4 MiB L2.
-constexpr int FBK = 32, FSTAGES = 4;
+constexpr int FBK = 32;
 constexpr int FOPER = 128 * FBK * 2;        // 8 KiB per operand per stage
 constexpr int FSTAGE = 2 * FOPER;           // 16 KiB
 
@@ -344,16 +345,22 @@ __device__ __forceinline__ bool fast_tile(const GemmParams& p, int gx, int gy, i
         __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0) */                                     \
         if ((t) + 1 < nk) {                                                                           \
             /* s_waitcnt simm16 (gfx9): vmcnt [3:0]+[15:14], expcnt [6:4], lgkmcnt [11:8]; the builtin   */ \
-            /* (unlike inline asm) is seen by the compiler's own wait-count bookkeeping                */ \
+            /* (unlike inline asm) is seen by the compiler's own wait-count bookkeeping.  Tiles t+2 ..   */ \
+            /* t+NST-1 (4 DMA each) may stay in flight; near the end fewer were issued.                 */ \
             if (ABL < 3) {                                                                            \
-            if (rem >= 2) __builtin_amdgcn_s_waitcnt(0x0F78);        /* vmcnt(8) */                     \
-            else if (rem == 1) __builtin_amdgcn_s_waitcnt(0x0F74);   /* vmcnt(4) */                     \
-            else __builtin_amdgcn_s_waitcnt(0x0F70);                 /* vmcnt(0) */                     \
+            if (rem >= NST - 2) __builtin_amdgcn_s_waitcnt(vm_only(4 * (NST - 2)));                   \
+            else if (rem >= 6) __builtin_amdgcn_s_waitcnt(vm_only(24));                               \
+            else if (rem == 5) __builtin_amdgcn_s_waitcnt(vm_only(20));                               \
+            else if (rem == 4) __builtin_amdgcn_s_waitcnt(vm_only(16));                               \
+            else if (rem == 3) __builtin_amdgcn_s_waitcnt(vm_only(12));                               \
+            else if (rem == 2) __builtin_amdgcn_s_waitcnt(vm_only(8));                                \
+            else if (rem == 1) __builtin_amdgcn_s_waitcnt(vm_only(4));                                \
+            else __builtin_amdgcn_s_waitcnt(vm_only(0));                                              \
             __builtin_amdgcn_s_barrier();                                                             \
             }                                                                                         \
-            if ((ABL < 1 || ABL == 4) && (t) + 4 < nk) issue((t) + 4);                                \
+            if ((ABL < 1 || ABL == 4) && (t) + NST < nk) issue((t) + NST);                            \
             if (ABL < 2) {                                                                            \
-            const char* st = smem + (((t) + 1) & (FSTAGES - 1)) * FSTAGE;                             \
+            const char* st = smem + (((t) + 1) & (NST - 1)) * FSTAGE;                                 \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
                 fa[(P) ^ 1][i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);             \
             _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
@@ -369,9 +376,14 @@ __device__ __forceinline__ bool fast_tile(const GemmParams& p, int gx, int gy, i
         }                                                                                             \
     }
 
+// s_waitcnt immediate for "vmcnt(n) only" (lgkmcnt and expcnt fields at their no-wait maxima)
+__device__ __host__ constexpr int vm_only(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+
+// NST: stages of the LDS ring (4: 64 KiB, two workgroups per CU; 8: 128 KiB, used when the grid has at most one
+// workgroup per CU anyway - twice the bytes in flight per CU lifts the latency-bound LDS-DMA rate).
 // ABL (timing experiments only, results are wrong for ABL != 0): 1 = no DMA in the main loop, 2 = also no
 // fragment reads, 3 = also no barrier / waits (bare MFMA loop), 4 = DMA + waits + barriers only (no reads, no MFMA)
-template <int ABL>
+template <int ABL, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, int gx, int gy, int stagger) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
@@ -401,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
     const int dma_off = wave * 1024;     // wave-uniform LDS offset of this wave's 64 chunks
 
     auto issue = [&](int kt) {
-        char* st = smem + (kt & (FSTAGES - 1)) * FSTAGE;
+        char* st = smem + (kt & (NST - 1)) * FSTAGE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * FBK),
@@ -423,15 +435,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
     const int b_off = FOPER + fswz(wn * 64 + frow, fk);
     bf16x8 fa[2][4], fb[2][4];
 
-    // prologue: tiles 0..3 in flight, tile 0 into fragment set 0
-    issue(0);
-    if (nk > 1) issue(1);
-    if (nk > 2) issue(2);
-    if (nk > 3) issue(3);
-    if (nk > 3) __builtin_amdgcn_s_waitcnt(0x0F7C);        // vmcnt(12)
-    else if (nk == 3) __builtin_amdgcn_s_waitcnt(0x0F78);  // vmcnt(8)
-    else if (nk == 2) __builtin_amdgcn_s_waitcnt(0x0F74);  // vmcnt(4)
-    else __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0)
+    // prologue: tiles 0..NST-1 in flight, tile 0 into fragment set 0
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+        if (i < nk) issue(i);
+    {
+        const int later = min(nk, NST) - 1;              // tiles issued after tile 0
+        if (later >= 7) __builtin_amdgcn_s_waitcnt(vm_only(28));
+        else if (later == 6) __builtin_amdgcn_s_waitcnt(vm_only(24));
+        else if (later == 5) __builtin_amdgcn_s_waitcnt(vm_only(20));
+        else if (later == 4) __builtin_amdgcn_s_waitcnt(vm_only(16));
+        else if (later == 3) __builtin_amdgcn_s_waitcnt(vm_only(12));
+        else if (later == 2) __builtin_amdgcn_s_waitcnt(vm_only(8));
+        else if (later == 1) __builtin_amdgcn_s_waitcnt(vm_only(4));
+        else __builtin_amdgcn_s_waitcnt(vm_only(0));
+    }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a_off + i * 1024);
@@ -462,20 +480,26 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
 }
 #undef EAVQA_FAST_STEP
 
+
 typedef void (*fast_kernel_t)(GemmParams, int, int, int);
 
 int launch_fast(const GemmParams& p, hipStream_t stream) {
-    static const fast_kernel_t kernels[5] = {gemm_bf16_fast_kernel<0>, gemm_bf16_fast_kernel<1>, gemm_bf16_fast_kernel<2>,
-                                             gemm_bf16_fast_kernel<3>, gemm_bf16_fast_kernel<4>};
+    static const fast_kernel_t kernels[7] = {gemm_bf16_fast_kernel<0, 4>, gemm_bf16_fast_kernel<1, 4>, gemm_bf16_fast_kernel<2, 4>,
+                                             gemm_bf16_fast_kernel<3, 4>, gemm_bf16_fast_kernel<4, 4>,
+                                             gemm_bf16_fast_kernel<0, 8>, gemm_bf16_fast_kernel<4, 8>};
     static bool configured = false;
     if (!configured) {
-        for (int i = 0; i < 5; ++i)
+        for (int i = 0; i < 7; ++i)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    CS_BYTES) != hipSuccess)
+                                    i >= 5 ? 8 * FSTAGE : CS_BYTES) != hipSuccess)
                 return EAVQA_E_LAUNCH;
         configured = true;
     }
-    const fast_kernel_t kernel = kernels[g_ablate <= 4 ? g_ablate : 0];
+    // deep ring (8 stages, one workgroup per CU): measured on MI355X to give no gain over 4 stages even for grids of one
+    // tile per CU (the LDS-DMA rate of a CU is a throughput cap, not a bytes-in-flight limit) - kept as an experiment knob
+    const bool deep = g_deep == 2;
+    const fast_kernel_t kernel = deep ? (g_ablate == 4 ? kernels[6] : kernels[5]) : kernels[g_ablate <= 4 ? g_ablate : 0];
+    const int lds_bytes = deep ? 8 * FSTAGE : CS_BYTES;
     // XCD grid gx x gy = 8 minimising the panels one XCD touches (rows + cols of its rectangle)
     int best_gx = 8, best_cost = 1 << 30;
     const int cand[4] = {8, 4, 2, 1};
@@ -486,7 +510,7 @@ int launch_fast(const GemmParams& p, hipStream_t stream) {
     }
     const int gx = best_gx, gy = 8 / gx;
     const int per_xcd = ((p.tiles_m + gx - 1) / gx) * ((p.tiles_n + gy - 1) / gy);
-    hipLaunchKernelGGL(kernel, dim3(per_xcd * 8), dim3(256), CS_BYTES, stream, p, gx, gy, g_stagger);
+    hipLaunchKernelGGL(kernel, dim3(per_xcd * 8), dim3(256), lds_bytes, stream, p, gx, gy, g_stagger);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }
@@ -870,7 +894,7 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 extern "C" void eavqa_debug_disable_fast_gemm(int disable) { g_disable_fast = disable != 0; }
-extern "C" void eavqa_debug_gemm_stagger(int units) { g_stagger = units & 0xff; g_ablate = (units >> 8) & 7; g_big_mode = (units >> 16) & 3; }
+extern "C" void eavqa_debug_gemm_stagger(int units) { g_stagger = units & 0xff; g_ablate = (units >> 8) & 7; g_big_mode = (units >> 16) & 3; g_deep = (units >> 20) & 3; }
 
 extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                           const void* A, int64_t lda, const void* B, int64_t ldb,

@@ -34,10 +34,12 @@ def main():
     ap.add_argument("--stagger", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation variant of the fast kernel (wrong results)")
     ap.add_argument("--big", type=int, default=0, help="0 auto, 1 never 256x256, 2 always 256x256")
+    ap.add_argument("--deep", type=int, default=0, help="8-stage ring: 0 auto, 1 never, 2 always")
+    ap.add_argument("--check", action="store_true", help="compare the result with a torch matmul")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
     _lib.load().eavqa_debug_disable_fast_gemm(int(args.general))
-    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8) | (args.big << 16))
+    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8) | (args.big << 16) | (args.deep << 20))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
     for M, N, K, what in SHAPES:
@@ -51,6 +53,11 @@ def main():
             kw = dict(bias=torch.zeros(N, device=dev), act="gelu_new", aux_out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
         for _ in range(3):
             ops.gemm(a, b, out=out, **kw)
+        if args.check and not kw:
+            ref = (a[:256].float() @ b.float().T)
+            err = (out[:256].float() - ref).abs().max().item()
+            tail = (out[-64:].float() - a[-64:].float() @ b.float().T).abs().max().item()
+            print(f"    check: max|err| first 256 rows {err:.4f}, last 64 rows {tail:.4f} (|ref| ~ {ref.abs().max().item():.2f})")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         iters = max(5, min(args.iters, int(2e12 / (2.0 * M * N * K)) + 5))
         e0.record()
