@@ -365,8 +365,15 @@ def gemm_roofline(stepper, ops):
     n = len(recs)
     achieved = flops / secs / 1e12
     peak = 2500.0 if stepper.model.dtype == torch.bfloat16 else 157.3
-    return {"bound": "mfma", "kernel": "gemm_bf16_fast_kernel" if stepper.model.dtype == torch.bfloat16 else "gemm_f32_kernel",
-            "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+    # HBM bytes per GEMM launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    # in separate runs, FETCH_SIZE x 2 on gfx950, KiB units): tools/pmc_traffic.py -> profiles/round1_gemm_traffic.json
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "round1_gemm_traffic.json")
+    if stepper.model.dtype == torch.bfloat16 and os.path.exists(tfile):
+        with open(tfile) as f:
+            traffic = round(json.load(f)["bytes_per_launch"])
+    return {"bound": "mfma", "kernel": "eavqa_gemm: gemm_bf16_fast_kernel + gemm_bf16_big_kernel" if stepper.model.dtype == torch.bfloat16 else "gemm_f32_kernel",
+            "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
             "launches_per_step": n, "gflop_per_launch": round(flops / n / 1e9, 2), "avg_launch_us": round(secs / n * 1e6, 2),
             "gemm_ms_per_step": round(secs * 1e3, 3)}
 
