@@ -283,5 +283,48 @@ def main():
          **_np(clip.state_dict(), "w."))
 
 
+def formatter_golden():
+    """Strings produced by the reference ``InContextExampleFormatter`` (src/utils/in_context_examples.py:114-218) for every
+    format type, 0 and 2 in-context examples, joined and per-example modes.  The module imports ``clip`` (absent, un-pinned)
+    and ``easydict`` (absent) at the top: both are stubbed in memory, neither is used by the formatter."""
+    import json
+    clip = types.ModuleType("clip")
+    sys.modules.setdefault("clip", clip)
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+        __getattr__ = dict.__getitem__
+    ed.EasyDict = EasyDict
+    sys.modules.setdefault("easydict", ed)
+    sys.path.insert(0, "/root/reference/src/utils")
+    import in_context_examples as ice
+    # the inputs of src/utils/in_context_examples_test.py:9-51 (test DATA)
+    examples = [dict(question_id=508840006, img_key=508840, question="What color is the boys hat?", gold_answer="red"),
+                dict(question_id=135938002, img_key=135938, question="Is the man wearing a shirt?", gold_answer="no")]
+    query = dict(question_id=262148000, question="Where is he looking?", gold_answer="down")
+    out = {"examples": examples, "query": query, "cases": []}
+    for fmt in ice.InContextExampleFormatter.formats:
+        if fmt.endswith("_list"):
+            continue
+        for n in (0, 2):
+            for one_at_a_time in (False, True):
+                for ensemble in (False, True):
+                    f = ice.InContextExampleFormatter(fmt, pass_examples_through_encoder_one_at_a_time=one_at_a_time,
+                                                      ensemble_one_shots=ensemble)
+                    got = f.format_input([EasyDict(e) for e in examples[:n]], EasyDict(query))
+                    out["cases"].append(dict(format_type=fmt, n=n, one_at_a_time=one_at_a_time, ensemble=ensemble, output=got))
+    with open(os.path.join(HERE, "formatter.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(f"wrote formatter.json: {len(out['cases'])} cases")
+
+
 if __name__ == "__main__":
-    main()
+    if "--formatter-only" in sys.argv:
+        formatter_golden()
+    else:
+        main()
+        formatter_golden()
