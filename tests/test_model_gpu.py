@@ -255,3 +255,57 @@ def test_fewshot_generate_matches_oracle_fp32(arch, fixture, use_cache):
         with pytest.raises(ValueError, match="sentinel"):
             model.generate_fewshot(bad, prefix, mask, num_shots=n_img - 1, special_token_id=special, max_length=2,
                                    pad_token_id=pad, eos_token_id=None)
+
+
+def _tiny_lm(V=96, E=64, n_layer=2, n_head=4, n_pos=400, seed=3, arch="gpt2"):
+    from eavqa_amd.models.lm import LMConfig, random_init_state_dict
+    cfg = LMConfig(arch, n_layer, n_head, E, 4 * E if arch == "gpt2" else 96, V, n_pos, 1e-5, "gelu_new" if arch == "gpt2" else "relu",
+                   V - 1, None if arch == "gpt2" else 1)
+    sd = random_init_state_dict(cfg, seed, "cpu")
+    for k in sd:                      # HF init leaves biases at 0 and LayerNorm at 1/0: perturb so they are exercised
+        if k.endswith("bias") or "ln_" in k or "layer_norm" in k:
+            g = torch.Generator().manual_seed(hash(k) % 1000)
+            sd[k] = sd[k] + 0.1 * torch.randn(sd[k].shape, generator=g)
+    return cfg, sd
+
+
+@pytest.mark.parametrize("arch", ["gpt2", "opt"])
+@pytest.mark.parametrize("B,Tt,lens", [
+    (1, 1, [1]),                 # a single token
+    (3, 1, [1, 1, 1]),
+    (2, 300, [300, 17]),         # several attention tiles, one row mostly padding
+    (5, 33, [33, 1, 2, 32, 16]), # ragged, odd batch
+    (2, 8, [8, 0]),              # a row with NO attended text token (only the prefix is attended)
+])
+def test_edge_shapes_match_oracle_fp32(arch, B, Tt, lens):
+    """Ragged / degenerate batches through the packed training forward: loss, attended logits and mapper gradients
+    against the oracle (float32)."""
+    from eavqa_amd.models.clipcap import ClipCaptionPrefix
+    from eavqa_amd.models.lm import FrozenCausalLM
+    cfg, sd = _tiny_lm(arch=arch)
+    L, D = 3, 16
+    lm = FrozenCausalLM(cfg, sd, torch.float32, DEV)
+    torch.manual_seed(1)
+    model = ClipCaptionPrefix(prefix_length=L, prefix_size=D, mapping_type="mlp", lm=lm, dtype=torch.float32, device=DEV).train()
+    g = torch.Generator().manual_seed(B * 1000 + Tt)
+    pad = cfg.vocab - 1
+    ids = torch.randint(2, cfg.vocab - 2, (B, Tt), generator=g)
+    mask = (torch.arange(Tt)[None] < torch.tensor(lens)[:, None]).long()
+    ids = ids * mask + pad * (1 - mask)
+    labels = oracle.label_mask_cc(ids, pad)
+    prefix = torch.randn(B, D, generator=g)
+    out = model(question_tokens=ids, prefix=prefix, question_mask=mask, labels=labels)
+    mapper = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.clip_project.state_dict().items()}
+    ocfg = dict(arch=arch, n_layer=cfg.n_layer, n_head=cfg.n_head, act=cfg.act)
+    loss, logits = oracle.clipcap_forward(sd, ocfg, mapper, dict(prefix_length=L, mapping_type="mlp"), ids, prefix, mask, labels)
+    attended = torch.cat([torch.ones(B, L, dtype=torch.bool), mask.bool()], dim=1)
+    assert (out.logits.cpu()[attended] - logits.detach()[attended]).abs().max().item() <= 2e-4
+    if torch.isnan(loss):                       # no labelled position at all: mean over nothing, as torch
+        assert torch.isnan(out.loss).item()
+        return
+    assert abs(out.loss.item() - loss.item()) <= 5e-5
+    out.loss.backward()
+    loss.backward()
+    for k, p in model.clip_project.named_parameters():
+        want = mapper[k].grad
+        assert (p.grad.cpu() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item()), k
