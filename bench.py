@@ -294,7 +294,7 @@ def main():
 
     roof = None
     if not args.no_roofline:
-        roof = gemm_roofline(stepper, ops)      # every rank runs it (the step contains the all-reduce); rank 0 reports
+        roof = gemm_roofline(stepper, ops, args.workload)      # every rank runs it (the step contains the all-reduce); rank 0 reports
         if rank == 0:
             log(f"roofline pass done: {roof}")
     extra = None
@@ -331,7 +331,7 @@ def main():
         dist.destroy_process_group()
 
 
-def gemm_roofline(stepper, ops):
+def gemm_roofline(stepper, ops, workload="cfg2"):
     """HIP events (torch.cuda.Event records on the current stream = the stream eavqa_gemm launches on) around every
     GEMM launch of one extra step: achieved = algorithmic FLOPs per launch / average launch duration."""
     real = ops.gemm
@@ -369,7 +369,7 @@ def gemm_roofline(stepper, ops):
     # in separate runs, FETCH_SIZE x 2 on gfx950, KiB units): tools/pmc_traffic.py -> profiles/round1_gemm_traffic.json
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "round1_gemm_traffic.json")
-    if stepper.model.dtype == torch.bfloat16 and os.path.exists(tfile):
+    if workload == "cfg2" and stepper.model.dtype == torch.bfloat16 and os.path.exists(tfile):
         with open(tfile) as f:
             traffic = round(json.load(f)["bytes_per_launch"])
     return {"bound": "mfma", "kernel": "eavqa_gemm: gemm_bf16_fast_kernel + gemm_bf16_big_kernel" if stepper.model.dtype == torch.bfloat16 else "gemm_f32_kernel",
