@@ -260,6 +260,19 @@ __global__ __launch_bounds__(256) void row_plan_kernel(int B, int S, int pack, c
     }
 }
 
+// dst[c][r] = src[r][c] through a 64 x 64 LDS tile (pitch 65 elements): both sides move whole 128-byte rows
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, const T* src, int64_t lds_, T* dst, int64_t ldd) {
+    __shared__ T tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[(int64_t)(r0 + i) * lds_ + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < cols && r0 + tx < rows) dst[(int64_t)(c0 + i) * ldd + r0 + tx] = tile[tx][i];
+}
+
 __global__ void zero_kernel(int n, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = 0.f;
@@ -289,6 +302,17 @@ extern "C" int eavqa_copy_rows(int dtype, int B, int S, int cols, const void* sr
     else if (dtype == EAVQA_BF16)
         hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(B * S), dim3(256), 0, s, S, cols, (const bf16_t*)src, lds, src_batch_rows,
                            (bf16_t*)dst, ldd, dst_batch_rows, dst_row0);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_transpose(int dtype, int rows, int cols, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, void* stream) {
+    if (rows <= 0 || cols <= 0 || !src || !dst || ld_src < cols || ld_dst < rows) return EAVQA_E_ARG;
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32) hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, s, rows, cols, (const float*)src, ld_src, (float*)dst, ld_dst);
+    else if (dtype == EAVQA_BF16) hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, s, rows, cols, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst);
     else return EAVQA_E_DTYPE;
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;

@@ -123,6 +123,7 @@ class MLP(_MapperBase):
         flat = FlatParams(named, device, dtype)
         self._adopt(flat, "", {n: p for n, p in self.model.named_parameters(prefix="model")})
         self.dtype = dtype
+        self._w2t = None      # scratch: transposed bf16 copy of the second Linear for its dgrad
 
     def forward(self, x: Tensor) -> Tensor:
         """``x``: [..., D] float -> [..., E*L] in the compute dtype (differentiable w.r.t. the parameters)."""
@@ -155,7 +156,16 @@ class _MLPFunction(torch.autograd.Function):
         # layer 2: dW2[N,K] = dy^T h ; db2 = colsum(dy) ; dh = (dy W2) * tanh'(u)
         _wgrad(dy, h, fl.g("model.2.weight"), acc)
         ops.colsum(dy, fl.g("model.2.bias"), acc)
-        dh = ops.gemm(dy, fl.w("model.2.weight"), b_kc=False, act="tanh", aux_in=u)
+        # dh = (dy W2) * tanh'(u): W2 is [N=E*L, K=H] (k-contiguous for the forward); its dgrad sums over N, so stream a
+        # transposed copy (one HBM pass) through the k-contiguous kernels instead of transposing tile by tile in LDS
+        w2 = fl.w("model.2.weight")
+        if dy.shape[0] <= 64 and dy.dtype == torch.bfloat16 and w2.shape[0] % 32 == 0:
+            if mod._w2t is None:
+                mod._w2t = torch.empty((w2.shape[1], w2.shape[0]), device=w2.device, dtype=w2.dtype)
+            ops.transpose(w2, out=mod._w2t)
+            dh = ops.gemm(dy, mod._w2t, act="tanh", aux_in=u)
+        else:
+            dh = ops.gemm(dy, w2, b_kc=False, act="tanh", aux_in=u)
         _wgrad(dh, xT, fl.g("model.0.weight"), acc)
         ops.colsum(dh, fl.g("model.0.bias"), acc)
         fl.grad_live = True

@@ -282,3 +282,10 @@ def copy_rows(src: Tensor, dst: Tensor, B: int, S: int, cols: int, src_batch_row
 def colsum(x: Tensor, out: Tensor, accumulate: bool) -> None:
     rows, cols = x.shape
     call("eavqa_colsum", dtype_id(x.dtype), rows, cols, _p(x), _ld(x), _p(out), int(accumulate), _stream())
+
+
+def transpose(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    rows, cols = x.shape
+    y = out if out is not None else torch.empty((cols, rows), device=x.device, dtype=x.dtype)
+    call("eavqa_transpose", dtype_id(x.dtype), rows, cols, _p(x), _ld(x), _p(y), _ld(y), _stream())
+    return y

@@ -176,6 +176,9 @@ int eavqa_build_row_plan(int B, int S, int pack, const int32_t* mask, const int6
  * projection rows (the reference re-runs the whole sequence instead, clipcap.py:414-419). cols % 4 == 0. */
 int eavqa_copy_rows(int dtype, int B, int S, int cols, const void* src, int64_t lds, int64_t src_batch_rows,
                     void* dst, int64_t ldd, int64_t dst_batch_rows, int64_t dst_row0, void* stream);
+/* dst[c, r] = src[r, c] (`dtype` -> `dtype`): the k-contiguous copy of a trainable [N,K] weight that its dgrad GEMM streams
+ * (the frozen weights get theirs once at load; the MLP mapper's second Linear needs a fresh one per step). */
+int eavqa_transpose(int dtype, int rows, int cols, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, void* stream);
 /* out[c] (+)= sum_r x[r, c]  (float32 out; `dtype` in): bias gradients of the mapper's Linear layers and
  * the gradient of TransformerMapper.prefix_const (clipcap.py:235-237).  accumulate != 0 adds to out. */
 int eavqa_colsum(int dtype, int rows, int cols, const void* x, int64_t ldx, float* out, int accumulate, void* stream);

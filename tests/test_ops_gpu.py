@@ -512,3 +512,10 @@ def test_cross_entropy_with_row_labels(ops):
     loss, count, row_lse = ops.ce_fwd(logits, lab, V)
     ref = torch.nn.functional.cross_entropy(logits.cpu()[:, :V], lab.cpu(), ignore_index=-100)
     assert abs(loss.item() - ref.item()) <= 1e-5 and count.item() == 6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols", [(64, 64), (130, 70), (1, 5), (12800, 640)])
+def test_transpose(ops, dtype, rows, cols):
+    x = rnd(rows, cols, dtype=dtype, seed=1).to(DEV)
+    assert torch.equal(ops.transpose(x).cpu(), x.cpu().T)
