@@ -56,14 +56,16 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
 // accesses only (every tile of the hot shapes except the last row of tiles).
 // Geometry G: TPR threads cover one row of the staged tile (4 columns each), RPP rows per pass, NPASS passes, PITCH floats
 // per staged row.
-template <int TPR_, int RPP_, int NPASS_, int PITCH_> struct EpiGeo {
-    static constexpr int TPR = TPR_, RPP = RPP_, NPASS = NPASS_, PITCH = PITCH_;
+// ROWS < RPP * NPASS (tile widths that do not divide the block): threads beyond TPR * RPP idle, the last pass is cut at ROWS.
+template <int TPR_, int RPP_, int NPASS_, int PITCH_, int ROWS_ = RPP_ * NPASS_> struct EpiGeo {
+    static constexpr int TPR = TPR_, RPP = RPP_, NPASS = NPASS_, PITCH = PITCH_, ROWS = ROWS_;
 };
 using EpiGeo128 = EpiGeo<32, 8, 16, CS_PITCH>;      // 128 x 128 tile, 256 threads
 
 template <typename T, int ACT, int MODE, bool FULL, typename G>
 __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* Cs, int m0, int n0) {
     const int tid = threadIdx.x;
+    if (G::ROWS != G::RPP * G::NPASS && tid >= G::TPR * G::RPP) return;
     const int c4 = (tid % G::TPR) * 4;
     const int n = n0 + c4;
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -81,6 +83,7 @@ __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* 
     for (int pass = 0; pass < G::NPASS; ++pass) {
         const int row = (tid / G::TPR) + pass * G::RPP;
         const int m = m0 + row;
+        if (G::ROWS != G::RPP * G::NPASS && row >= G::ROWS) continue;
         if (!FULL && (m >= p.M || n >= p.N)) continue;
         const float4 a = *reinterpret_cast<const float4*>(&Cs[row * G::PITCH + c4]);
         float v[4] = {a.x, a.y, a.z, a.w};
@@ -132,7 +135,7 @@ __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* 
 
 template <typename T, int ACT, int MODE, typename G>
 __device__ __forceinline__ void epilogue_mode(const GemmParams& p, const float* Cs, int m0, int n0) {
-    constexpr int ROWS = G::RPP * G::NPASS, COLS = G::TPR * 4;
+    constexpr int ROWS = G::ROWS, COLS = G::TPR * 4;
     const bool full_tile = (m0 + ROWS <= p.M) && (n0 + COLS <= p.N) && p.vec_c && (!(p.aux_in || p.aux_out) || p.vec_aux) &&
                            (!p.residual || p.vec_res) && (!p.bias || p.vec_bias);
     if (full_tile) epilogue_body<T, ACT, MODE, true, G>(p, Cs, m0, n0);
@@ -358,7 +361,7 @@ __device__ __forceinline__ bool fast_tile(const GemmParams& p, int gx, int gy, i
             else __builtin_amdgcn_s_waitcnt(vm_only(0));                                              \
             __builtin_amdgcn_s_barrier();                                                             \
             }                                                                                         \
-            if ((ABL < 1 || ABL == 4) && (t) + NST < nk) issue((t) + NST);                            \
+            if ((ABL < 1 || ABL >= 4) && (t) + NST < nk) issue((t) + NST);                            \
             if (ABL < 2) {                                                                            \
             const char* st = smem + (((t) + 1) & (NST - 1)) * FSTAGE;                                 \
             _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
         for (int i = 0; i < 2; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * FBK),
                                              (__attribute__((address_space(3))) void*)(st + dma_off + i * 4096), 16, 0, 0);
+            if (ABL != 5 || i == 0 || lane < 16)     // ABL 5: the DMA pattern of a 128 x 80 tile (quarter-wave last piece)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * FBK),
                                              (__attribute__((address_space(3))) void*)(st + FOPER + dma_off + i * 4096), 16, 0, 0);
         }
@@ -484,21 +488,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
 typedef void (*fast_kernel_t)(GemmParams, int, int, int);
 
 int launch_fast(const GemmParams& p, hipStream_t stream) {
-    static const fast_kernel_t kernels[7] = {gemm_bf16_fast_kernel<0, 4>, gemm_bf16_fast_kernel<1, 4>, gemm_bf16_fast_kernel<2, 4>,
+    static const fast_kernel_t kernels[8] = {gemm_bf16_fast_kernel<0, 4>, gemm_bf16_fast_kernel<1, 4>, gemm_bf16_fast_kernel<2, 4>,
                                              gemm_bf16_fast_kernel<3, 4>, gemm_bf16_fast_kernel<4, 4>,
-                                             gemm_bf16_fast_kernel<0, 8>, gemm_bf16_fast_kernel<4, 8>};
+                                             gemm_bf16_fast_kernel<0, 8>, gemm_bf16_fast_kernel<4, 8>, gemm_bf16_fast_kernel<5, 4>};
     static bool configured = false;
     if (!configured) {
-        for (int i = 0; i < 7; ++i)
+        for (int i = 0; i < 8; ++i)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    i >= 5 ? 8 * FSTAGE : CS_BYTES) != hipSuccess)
+                                    (i == 5 || i == 6) ? 8 * FSTAGE : CS_BYTES) != hipSuccess)
                 return EAVQA_E_LAUNCH;
         configured = true;
     }
     // deep ring (8 stages, one workgroup per CU): measured on MI355X to give no gain over 4 stages even for grids of one
     // tile per CU (the LDS-DMA rate of a CU is a throughput cap, not a bytes-in-flight limit) - kept as an experiment knob
     const bool deep = g_deep == 2;
-    const fast_kernel_t kernel = deep ? (g_ablate == 4 ? kernels[6] : kernels[5]) : kernels[g_ablate <= 4 ? g_ablate : 0];
+    const fast_kernel_t kernel = deep ? (g_ablate == 4 ? kernels[6] : kernels[5]) : kernels[g_ablate <= 4 ? g_ablate : (g_ablate == 5 ? 7 : 0)];
     const int lds_bytes = deep ? 8 * FSTAGE : CS_BYTES;
     // XCD grid gx x gy = 8 minimising the panels one XCD touches (rows + cols of its rectangle)
     int best_gx = 8, best_cost = 1 << 30;
@@ -515,6 +519,194 @@ int launch_fast(const GemmParams& p, hipStream_t stream) {
     return EAVQA_OK;
 }
 
+
+// ================================================= bf16 narrow tiles ===
+// 128 x (16 NF) output tile, NF = 5 or 6, same LDS-DMA ring and register-prefetch pipeline as the fast kernel.  Why: a CU
+// takes in its operand tiles at a fixed rate (measured ~52 GB/s, whether one or two workgroups share the CU), so a GEMM
+// whose 128 x 128 grid leaves CUs idle (N = 1280 at M ~ 2000: 160 tiles for 256 CUs) finishes sooner with MORE, narrower
+// tiles: 128 x 80 gives 256 tiles and each CU moves (128 + 80) / (128 + 128) of the bytes.
+//   * waves 4 x 1: wave w owns rows 32 w .. 32 w + 31 (2 A fragments) and all 16 NF columns (NF B fragments):
+//     2 NF MFMAs per K-step against 2 + NF ds_read_b128;
+//   * the B stage is 16 NF rows x 64 B = NF KiB: one full-wave DMA per wave (rows 0..63) plus one piece of
+//     16 (NF - 4) lanes per wave for the remaining rows, so that every wave issues the same 4 DMAs per stage and the
+//     counted vmcnt waits stay exact.
+template <int NF>
+__device__ __forceinline__ bool narrow_tile(int gx, int gy, int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int xi = xcd % gx, yi = xcd / gx;
+    const int qm = tiles_m / gx, rm = tiles_m % gx, qn = tiles_n / gy, rn = tiles_n % gy;
+    const int m_begin = xi * qm + min(xi, rm), m_cnt = qm + (xi < rm ? 1 : 0);
+    const int n_begin = yi * qn + min(yi, rn), n_cnt = qn + (yi < rn ? 1 : 0);
+    if (m_cnt == 0 || local >= m_cnt * n_cnt) return false;
+    tm = m_begin + local % m_cnt;
+    tn = n_begin + local / m_cnt;
+    return true;
+}
+
+#define EAVQA_NARROW_STEP(P, t)                                                                       \
+    {                                                                                                 \
+        const int rem = nk - 2 - (t);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
+        __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0): fragment set P is complete */         \
+        if ((t) + 1 < nk) {                                                                           \
+            if (rem >= 2) __builtin_amdgcn_s_waitcnt(vm_only(8));                                     \
+            else if (rem == 1) __builtin_amdgcn_s_waitcnt(vm_only(4));                                \
+            else __builtin_amdgcn_s_waitcnt(vm_only(0));                                              \
+            __builtin_amdgcn_s_barrier();                                                             \
+            if ((t) + 4 < nk) issue((t) + 4);                                                         \
+            const char* st = smem + (((t) + 1) & 3) * FSTAGE;                                         \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
+                fa[(P) ^ 1][i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);             \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j)                                            \
+                fb[(P) ^ 1][j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);             \
+        }                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j)                                            \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[P][i], fb[P][j], acc[i][j], 0, 0, 0); \
+    }
+
+template <int NF>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_narrow_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
+    static_assert(NF > 4 && NF < 8, "one full + one partial B piece per wave");
+    constexpr int BNn = 16 * NF, XL = 16 * (NF - 4);        // tile width; lanes of the partial B piece
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tm, tn;
+    if (!narrow_tile<NF>(gx, gy, tiles_m, tiles_n, tm, tn)) return;
+    const int m0 = tm * BM, n0 = tn * BNn;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
+    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
+
+    const bf16_t* asrc[2];
+    const bf16_t* bsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c >> 2, pc = c & 3;
+        asrc[i] = A + (int64_t)min(m0 + row, p.M - 1) * p.lda + (pc ^ ((-(row >> 2)) & 3)) * 8;
+    }
+    {
+        const int c0 = tid, r0 = c0 >> 2, q0 = c0 & 3;
+        bsrc[0] = B + (int64_t)min(n0 + r0, p.N - 1) * p.ldb + (q0 ^ ((-(r0 >> 2)) & 3)) * 8;
+        const int c1 = 256 + wave * XL + min(lane, XL - 1), r1 = c1 >> 2, q1 = c1 & 3;
+        bsrc[1] = B + (int64_t)min(n0 + r1, p.N - 1) * p.ldb + (q1 ^ ((-(r1 >> 2)) & 3)) * 8;
+    }
+    const int dma_off = wave * 1024;
+    const int dma_off_x = FOPER + 4096 + wave * XL * 16;
+
+    auto issue = [&](int kt) {
+        char* st = smem + (kt & 3) * FSTAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * FBK),
+                                             (__attribute__((address_space(3))) void*)(st + dma_off + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[0] + kt * FBK),
+                                         (__attribute__((address_space(3))) void*)(st + FOPER + dma_off), 16, 0, 0);
+        if (lane < XL)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[1] + kt * FBK),
+                                             (__attribute__((address_space(3))) void*)(st + dma_off_x), 16, 0, 0);
+    };
+
+    f32x4 acc[2][NF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = p.K / FBK;
+    const int frow = lane & 15, fk = lane >> 4;
+    const int a_off = fswz(wave * 32 + frow, fk);          // + i * 16 rows * 64 B
+    const int b_off = FOPER + fswz(frow, fk);              // + j * 16 rows * 64 B
+    bf16x8 fa[2][2], fb[2][NF];
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < nk) issue(i);
+    {
+        const int later = min(nk, 4) - 1;
+        if (later == 3) __builtin_amdgcn_s_waitcnt(vm_only(12));
+        else if (later == 2) __builtin_amdgcn_s_waitcnt(vm_only(8));
+        else if (later == 1) __builtin_amdgcn_s_waitcnt(vm_only(4));
+        else __builtin_amdgcn_s_waitcnt(vm_only(0));
+    }
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a_off + i * 1024);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(smem + b_off + j * 1024);
+
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        EAVQA_NARROW_STEP(0, t)
+        EAVQA_NARROW_STEP(1, t + 1)
+    }
+    if (t < nk) EAVQA_NARROW_STEP(0, t)
+    __syncthreads();
+
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 32 + i * 16 + (lane >> 4) * 4 + r;
+                const int col = j * 16 + (lane & 15);
+                Cs[row * CS_PITCH + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    constexpr int TPR = 4 * NF, RPP = 256 / TPR, NPASS = (BM + RPP - 1) / RPP;
+    epilogue<bf16_t, EpiGeo<TPR, RPP, NPASS, CS_PITCH, BM>>(p, Cs, m0, n0);
+}
+#undef EAVQA_NARROW_STEP
+
+template <int NF>
+int launch_narrow(const GemmParams& p, hipStream_t stream) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_narrow_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                100 * 1024) != hipSuccess)
+            return EAVQA_E_LAUNCH;
+        configured = true;
+    }
+    const int tiles_m = p.tiles_m, tiles_n = (p.N + 16 * NF - 1) / (16 * NF);
+    int best_gx = 8, best_cost = 1 << 30;
+    const int cand[4] = {8, 4, 2, 1};
+    for (int c = 0; c < 4; ++c) {
+        const int gx = cand[c], gy = 8 / gx;
+        const int cost = ((tiles_m + gx - 1) / gx) * 128 + ((tiles_n + gy - 1) / gy) * 16 * NF;
+        if (cost < best_cost) { best_cost = cost; best_gx = gx; }
+    }
+    const int gx = best_gx, gy = 8 / gx;
+    const int per_xcd = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
+    // experiment knob (deep == 3): ask for > 80 KiB so that at most one workgroup fits a CU
+    hipLaunchKernelGGL(gemm_bf16_narrow_kernel<NF>, dim3(per_xcd * 8), dim3(256), g_deep == 3 ? 100 * 1024 : CS_BYTES, stream, p, gx, gy,
+                       tiles_m, tiles_n);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+// 0 = choose by shape, 1 = never, 5 / 6 = always that NF
+int g_narrow_mode = 0;
+
+// Relative time of a grid of `tiles` (bm x bn) tiles: a CU takes in operand bytes at a fixed rate (measured: K = 5120 takes
+// 50 / 51 / 54 us on 80 / 160 / 256 tiles of 128 x 128 and 103 us on 512: two co-resident workgroups share the rate of one),
+// so time ~ rounds of 256 workgroups x bytes per workgroup and K-step.
+inline float tile_cost(int tiles, int bm, int bn) { return ((tiles + 255) / 256) * float(bm + bn); }
+
+// narrow tile width (0 = keep 128 x 128) for a k-contiguous bf16 GEMM
+int narrow_choice(const GemmParams& p) {
+    if (g_narrow_mode == 1) return 0;
+    if (g_narrow_mode == 5 || g_narrow_mode == 6) return g_narrow_mode;
+    int best = 0;
+    float best_cost = tile_cost(p.tiles_m * p.tiles_n, 128, 128);
+    for (int nf = 6; nf >= 5; --nf) {
+        const float c = tile_cost(p.tiles_m * ((p.N + 16 * nf - 1) / (16 * nf)), 128, 16 * nf);
+        if (c < best_cost * 0.97f) { best_cost = c; best = nf; }
+    }
+    return best;
+}
 
 // ====================================================== bf16 big tiles ===
 // 256 x 256 output tile per 1024-thread workgroup (16 waves as 4 x 4, 64 x 64 each, four waves per SIMD) for GEMMs
@@ -894,7 +1086,10 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 extern "C" void eavqa_debug_disable_fast_gemm(int disable) { g_disable_fast = disable != 0; }
-extern "C" void eavqa_debug_gemm_stagger(int units) { g_stagger = units & 0xff; g_ablate = (units >> 8) & 7; g_big_mode = (units >> 16) & 3; g_deep = (units >> 20) & 3; }
+extern "C" void eavqa_debug_gemm_stagger(int units) {
+    g_stagger = units & 0xff; g_ablate = (units >> 8) & 7; g_big_mode = (units >> 16) & 3; g_deep = (units >> 20) & 3;
+    g_narrow_mode = (units >> 24) & 7;
+}
 
 extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                           const void* A, int64_t lda, const void* B, int64_t ldb,
@@ -934,7 +1129,12 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
     if (dtype == EAVQA_BF16) {
         if (a_kc && b_kc && !g_disable_fast && M <= 64 && (K % 32) == 0 && N >= 64) return launch_skinny(p, s);
         if (a_kc && b_kc && !g_disable_fast && use_big(p)) return launch_big(p, s);
-        if (a_kc && b_kc && (K % FBK) == 0 && !g_disable_fast) return launch_fast(p, s);
+        if (a_kc && b_kc && (K % FBK) == 0 && !g_disable_fast) {
+            const int nf = narrow_choice(p);
+            if (nf == 5) return launch_narrow<5>(p, s);
+            if (nf == 6) return launch_narrow<6>(p, s);
+            return launch_fast(p, s);
+        }
         if (a_kc && b_kc) return launch(gemm_bf16_kernel<true, true>, p, s);
         if (a_kc && !b_kc) return launch(gemm_bf16_kernel<true, false>, p, s);
         if (!a_kc && b_kc) return launch(gemm_bf16_kernel<false, true>, p, s);

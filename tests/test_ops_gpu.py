@@ -43,14 +43,17 @@ ACTS = {
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=["fast", "general", "big"])
+@pytest.fixture(params=["fast", "general", "big", "narrow5", "narrow6"])
 def gemm_path(request):
     """bf16 k-contiguous GEMMs take the 128x128 LDS-DMA kernel (K % 32 == 0) or the 256x256 one (K % 64 == 0, chosen by
-    shape); run every case through the general kernel, the 128x128 kernel and (forced) the 256x256 kernel."""
+    shape) or a narrow 128x80 / 128x96 one (chosen by shape); run every case through the general kernel, the 128x128
+    kernel and (forced) the 256x256 and narrow kernels."""
     from eavqa_amd import _lib
     lib = _lib.load()
     lib.eavqa_debug_disable_fast_gemm(int(request.param == "general"))
-    lib.eavqa_debug_gemm_stagger({"fast": 1, "general": 1, "big": 2}[request.param] << 16)
+    big = {"fast": 1, "general": 1, "big": 2, "narrow5": 1, "narrow6": 1}[request.param]
+    narrow = {"fast": 1, "general": 1, "big": 1, "narrow5": 5, "narrow6": 6}[request.param]
+    lib.eavqa_debug_gemm_stagger((big << 16) | (narrow << 24))
     yield request.param
     lib.eavqa_debug_disable_fast_gemm(0)
     lib.eavqa_debug_gemm_stagger(0)

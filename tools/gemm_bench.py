@@ -22,6 +22,8 @@ SHAPES = [  # (M, N, K, what)
     (2688, 3840, 1280, "qkv fwd"), (2688, 1280, 1280, "proj fwd / dctx"), (2688, 5120, 1280, "fc1 fwd / du"),
     (2688, 1280, 5120, "fc2 fwd / da2"), (2688, 1280, 3840, "dqkv->da"), (2688, 50257, 1280, "lm_head fwd"),
     (2688, 1280, 50304, "lm_head dgrad"), (3200, 2304, 768, "vit qkv"), (3200, 768, 768, "vit proj"),
+    (1024, 1280, 5120, "probe 80 tiles"), (2048, 1280, 5120, "probe 160 tiles"), (2048, 2048, 5120, "probe 256 tiles"),
+    (2048, 3072, 5120, "probe 384 tiles"), (2048, 4096, 5120, "probe 512 tiles"), (4096, 4096, 5120, "probe 1024 tiles"),
     (3200, 3072, 768, "vit fc1"), (3200, 768, 3072, "vit fc2"), (4096, 4096, 4096, "square 4k"), (8192, 8192, 8192, "square 8k"),
 ]
 
@@ -34,12 +36,14 @@ def main():
     ap.add_argument("--stagger", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation variant of the fast kernel (wrong results)")
     ap.add_argument("--big", type=int, default=0, help="0 auto, 1 never 256x256, 2 always 256x256")
+    ap.add_argument("--narrow", type=int, default=0, help="0 auto, 1 never a narrow tile, 5 / 6 always 128x80 / 128x96")
     ap.add_argument("--deep", type=int, default=0, help="8-stage ring: 0 auto, 1 never, 2 always")
     ap.add_argument("--check", action="store_true", help="compare the result with a torch matmul")
+    ap.add_argument("--cold", action="store_true", help="rotate over enough copies of the weight to defeat L2 + Infinity Cache")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
     _lib.load().eavqa_debug_disable_fast_gemm(int(args.general))
-    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8) | (args.big << 16) | (args.deep << 20))
+    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8) | (args.big << 16) | (args.deep << 20) | (args.narrow << 24))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
     for M, N, K, what in SHAPES:
@@ -48,6 +52,9 @@ def main():
         a = torch.randn(M, K, device=dev).to(torch.bfloat16)
         b = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        bs = [b]
+        if args.cold:
+            bs = [b.clone() for _ in range(max(2, int(6e8 / (2.0 * N * K)) + 1))]
         kw = {}
         if args.epilogue:
             kw = dict(bias=torch.zeros(N, device=dev), act="gelu_new", aux_out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
@@ -61,8 +68,8 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         iters = max(5, min(args.iters, int(2e12 / (2.0 * M * N * K)) + 5))
         e0.record()
-        for _ in range(iters):
-            ops.gemm(a, b, out=out, **kw)
+        for i in range(iters):
+            ops.gemm(a, bs[i % len(bs)], out=out, **kw)
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / iters
