@@ -495,7 +495,7 @@ int launch_fast(const GemmParams& p, hipStream_t stream) {
     if (!configured) {
         for (int i = 0; i < 8; ++i)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (i == 5 || i == 6) ? 8 * FSTAGE : CS_BYTES) != hipSuccess)
+                                    8 * FSTAGE) != hipSuccess)
                 return EAVQA_E_LAUNCH;
         configured = true;
     }
@@ -520,19 +520,33 @@ int launch_fast(const GemmParams& p, hipStream_t stream) {
 }
 
 
-// ================================================= bf16 narrow tiles ===
-// 128 x (16 NF) output tile, NF = 5 or 6, same LDS-DMA ring and register-prefetch pipeline as the fast kernel.  Why: a CU
-// takes in its operand tiles at a fixed rate (measured ~52 GB/s, whether one or two workgroups share the CU), so a GEMM
-// whose 128 x 128 grid leaves CUs idle (N = 1280 at M ~ 2000: 160 tiles for 256 CUs) finishes sooner with MORE, narrower
-// tiles: 128 x 80 gives 256 tiles and each CU moves (128 + 80) / (128 + 128) of the bytes.
-//   * waves 4 x 1: wave w owns rows 32 w .. 32 w + 31 (2 A fragments) and all 16 NF columns (NF B fragments):
-//     2 NF MFMAs per K-step against 2 + NF ds_read_b128;
-//   * the B stage is 16 NF rows x 64 B = NF KiB: one full-wave DMA per wave (rows 0..63) plus one piece of
-//     16 (NF - 4) lanes per wave for the remaining rows, so that every wave issues the same 4 DMAs per stage and the
-//     counted vmcnt waits stay exact.
-template <int NF>
-__device__ __forceinline__ bool narrow_tile(int gx, int gy, int tiles_m, int tiles_n, int& tm, int& tn) {
+// ============================================== bf16 shaped tiles ===
+// (16 MF WM) x (16 NF WN) output tile per workgroup of WM x WN waves, same LDS-DMA ring (BK = 32, 4 stages, counted vmcnt,
+// one s_barrier per K-step) and register-prefetched fragments as the fast kernel.  Why other shapes: a CU takes in its
+// operand tiles at a fixed rate (measured ~52 GB/s into LDS whether one or two workgroups share the CU: K = 5120 takes
+// 50 / 51 / 54 us on 80 / 160 / 256 tiles of 128 x 128 and 103 us on 512), so the time of a GEMM is
+//     rounds of 256 workgroups  x  (BM + BN) bytes per workgroup and K-step
+// and the best tile is the one whose grid just fills the 256 CUs once:
+//   * narrow 128 x 80 / 128 x 96 (4 x 1 waves, 2 x NF fragments): N = 1280 at M ~ 2000 is 160 tiles of 128 x 128 (96 CUs
+//     idle) but 256 tiles of 128 x 80, each moving 208 / 256 of the bytes;
+//   * tall 256 x 128 / 256 x 160 / 256 x 192 (4 x 2 waves, 4 x NF fragments): N = 3840 at M ~ 2000 is 480 tiles of
+//     128 x 128 (two rounds) but 240 of 256 x 128 (one round at 384 / 512 of the bytes).
+// The B stage (16 NF WN rows x 64 B) is moved by BFULL full-wave DMAs per wave plus, when 4 BN is not a multiple of the
+// workgroup size, one piece of BREM lanes per wave, so that every wave issues the same number of DMAs per stage and the
+// counted vmcnt waits stay exact.  The C tile leaves through LDS in passes of as many wave rows as fit the ring's bytes.
+// block -> tile.  gx > 0: XCD (blockIdx % 8) owns the rectangle (xi, yi) of a gx x gy split of the tile grid (the panels it
+// re-reads stay in its L2); gx == 0: XCD owns a contiguous run of ceil / floor(tiles / 8) tiles in M-fastest order (used
+// when a rectangle split would put more than 32 tiles on one XCD although the grid fits the chip once).
+__device__ __forceinline__ bool shaped_tile(int gx, int gy, int tiles_m, int tiles_n, int& tm, int& tn) {
     const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    if (gx == 0) {
+        const int nwg = tiles_m * tiles_n, q = nwg >> 3, r = nwg & 7;
+        if (local >= q + (xcd < r ? 1 : 0)) return false;
+        const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+        tm = wgid % tiles_m;
+        tn = wgid / tiles_m;
+        return true;
+    }
     const int xi = xcd % gx, yi = xcd / gx;
     const int qm = tiles_m / gx, rm = tiles_m % gx, qn = tiles_n / gy, rn = tiles_n % gy;
     const int m_begin = xi * qm + min(xi, rm), m_cnt = qm + (xi < rm ? 1 : 0);
@@ -543,169 +557,199 @@ __device__ __forceinline__ bool narrow_tile(int gx, int gy, int tiles_m, int til
     return true;
 }
 
-#define EAVQA_NARROW_STEP(P, t)                                                                       \
+// host side of shaped_tile: the split and the number of workgroups the fullest XCD receives
+struct GridPlan { int gx, gy, per_xcd; };
+inline GridPlan plan_grid(int tiles_m, int tiles_n, int bm, int bn) {
+    GridPlan g{8, 1, 0};
+    int best_cost = 1 << 30;
+    const int cand[4] = {8, 4, 2, 1};
+    for (int c = 0; c < 4; ++c) {
+        const int gx = cand[c], gy = 8 / gx;
+        const int cost = ((tiles_m + gx - 1) / gx) * bm + ((tiles_n + gy - 1) / gy) * bn;     // operand rows one XCD touches
+        if (cost < best_cost) { best_cost = cost; g.gx = gx; g.gy = gy; }
+    }
+    g.per_xcd = ((tiles_m + g.gx - 1) / g.gx) * ((tiles_n + g.gy - 1) / g.gy);
+    const int even = (tiles_m * tiles_n + 7) / 8;
+    if ((g.per_xcd + 31) / 32 > (even + 31) / 32) { g.gx = 0; g.gy = 0; g.per_xcd = even; }
+    return g;
+}
+
+template <int WM, int WN, int MF, int NF> struct TileGeo {
+    static constexpr int NT = 64 * WM * WN, NW = WM * WN;
+    static constexpr int TBM = 16 * MF * WM, TBN = 16 * NF * WN;
+    static constexpr int AFULL = 4 * TBM / NT, BFULL = 4 * TBN / NT;
+    static constexpr int BREM = (4 * TBN - BFULL * NT) / NW;             // lanes of the partial B piece per wave
+    static constexpr int NDMA = AFULL + BFULL + (BREM > 0 ? 1 : 0);      // DMA instructions per wave and stage
+    static constexpr int AOPER = TBM * 64, STAGE = (TBM + TBN) * 64, RING = 4 * STAGE;
+    static constexpr int PITCH = TBN + 4;
+    // wave rows staged per epilogue pass: the most that fit the ring
+    static constexpr int SP = (16 * MF * WM * PITCH * 4 <= RING) ? WM : ((16 * MF * (WM / 2) * PITCH * 4 <= RING) ? WM / 2 : 1);
+    static constexpr int PROWS = 16 * MF * SP;
+    static constexpr int TPR = TBN / 4, RPP = NT / TPR, NPASS = (PROWS + RPP - 1) / RPP;
+    static_assert(4 * TBM == AFULL * NT, "A stage must split evenly");
+    static_assert(BFULL * NT + BREM * NW == 4 * TBN && BREM < 64, "B stage: full pieces + one partial piece per wave");
+    static_assert(16 * MF * PITCH * 4 <= RING, "one wave row of C must fit the ring");
+    static_assert(WM % SP == 0, "passes cover whole wave rows");
+};
+
+#define EAVQA_SHAPED_STEP(P, t)                                                                       \
     {                                                                                                 \
         const int rem = nk - 2 - (t);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                            \
         __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0): fragment set P is complete */         \
         if ((t) + 1 < nk) {                                                                           \
-            if (rem >= 2) __builtin_amdgcn_s_waitcnt(vm_only(8));                                     \
-            else if (rem == 1) __builtin_amdgcn_s_waitcnt(vm_only(4));                                \
+            if (rem >= 2) __builtin_amdgcn_s_waitcnt(vm_only(2 * G::NDMA));                           \
+            else if (rem == 1) __builtin_amdgcn_s_waitcnt(vm_only(G::NDMA));                          \
             else __builtin_amdgcn_s_waitcnt(vm_only(0));                                              \
             __builtin_amdgcn_s_barrier();                                                             \
             if ((t) + 4 < nk) issue((t) + 4);                                                         \
-            const char* st = smem + (((t) + 1) & 3) * FSTAGE;                                         \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
+            const char* st = smem + (((t) + 1) & 3) * G::STAGE;                                       \
+            _Pragma("unroll") for (int i = 0; i < MF; ++i)                                            \
                 fa[(P) ^ 1][i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 1024);             \
             _Pragma("unroll") for (int j = 0; j < NF; ++j)                                            \
                 fb[(P) ^ 1][j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 1024);             \
         }                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+        _Pragma("unroll") for (int i = 0; i < MF; ++i)                                                \
             _Pragma("unroll") for (int j = 0; j < NF; ++j)                                            \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[P][i], fb[P][j], acc[i][j], 0, 0, 0); \
     }
 
-template <int NF>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_narrow_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
-    static_assert(NF > 4 && NF < 8, "one full + one partial B piece per wave");
-    constexpr int BNn = 16 * NF, XL = 16 * (NF - 4);        // tile width; lanes of the partial B piece
+template <int WM, int WN, int MF, int NF>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_bf16_shaped_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
+    using G = TileGeo<WM, WN, MF, NF>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
-    if (!narrow_tile<NF>(gx, gy, tiles_m, tiles_n, tm, tn)) return;
-    const int m0 = tm * BM, n0 = tn * BNn;
+    if (!shaped_tile(gx, gy, tiles_m, tiles_n, tm, tn)) return;
+    const int m0 = tm * G::TBM, n0 = tn * G::TBN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
     const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
     const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
 
-    const bf16_t* asrc[2];
-    const bf16_t* bsrc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int c = tid + 256 * i;
+    // per-lane DMA sources; chunk c of an operand image is (row c >> 2, physical 16-byte slot c & 3)
+    auto src_of = [&](const bf16_t* X, int64_t ld, int row0, int rows_max, int c) {
         const int row = c >> 2, pc = c & 3;
-        asrc[i] = A + (int64_t)min(m0 + row, p.M - 1) * p.lda + (pc ^ ((-(row >> 2)) & 3)) * 8;
-    }
-    {
-        const int c0 = tid, r0 = c0 >> 2, q0 = c0 & 3;
-        bsrc[0] = B + (int64_t)min(n0 + r0, p.N - 1) * p.ldb + (q0 ^ ((-(r0 >> 2)) & 3)) * 8;
-        const int c1 = 256 + wave * XL + min(lane, XL - 1), r1 = c1 >> 2, q1 = c1 & 3;
-        bsrc[1] = B + (int64_t)min(n0 + r1, p.N - 1) * p.ldb + (q1 ^ ((-(r1 >> 2)) & 3)) * 8;
-    }
-    const int dma_off = wave * 1024;
-    const int dma_off_x = FOPER + 4096 + wave * XL * 16;
+        return X + (int64_t)min(row0 + row, rows_max - 1) * ld + (pc ^ ((-(row >> 2)) & 3)) * 8;
+    };
+    const bf16_t* asrc[G::AFULL];
+    const bf16_t* bsrc[G::BFULL + 1];
+#pragma unroll
+    for (int i = 0; i < G::AFULL; ++i) asrc[i] = src_of(A, p.lda, m0, p.M, tid + G::NT * i);
+#pragma unroll
+    for (int i = 0; i < G::BFULL; ++i) bsrc[i] = src_of(B, p.ldb, n0, p.N, tid + G::NT * i);
+    bsrc[G::BFULL] = src_of(B, p.ldb, n0, p.N, G::BFULL * G::NT + wave * G::BREM + min(lane, max(G::BREM, 1) - 1));
+    const int dma_off = wave * 1024;                                        // + i * NT * 16 for full pieces
+    const int dma_off_x = G::AOPER + G::BFULL * G::NT * 16 + wave * G::BREM * 16;
 
     auto issue = [&](int kt) {
-        char* st = smem + (kt & 3) * FSTAGE;
+        char* st = smem + (kt & 3) * G::STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < G::AFULL; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * FBK),
-                                             (__attribute__((address_space(3))) void*)(st + dma_off + i * 4096), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[0] + kt * FBK),
-                                         (__attribute__((address_space(3))) void*)(st + FOPER + dma_off), 16, 0, 0);
-        if (lane < XL)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[1] + kt * FBK),
+                                             (__attribute__((address_space(3))) void*)(st + dma_off + i * G::NT * 16), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < G::BFULL; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * FBK),
+                                             (__attribute__((address_space(3))) void*)(st + G::AOPER + dma_off + i * G::NT * 16), 16, 0, 0);
+        if (G::BREM > 0 && lane < G::BREM)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[G::BFULL] + kt * FBK),
                                              (__attribute__((address_space(3))) void*)(st + dma_off_x), 16, 0, 0);
     };
 
-    f32x4 acc[2][NF];
+    f32x4 acc[MF][NF];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int nk = p.K / FBK;
     const int frow = lane & 15, fk = lane >> 4;
-    const int a_off = fswz(wave * 32 + frow, fk);          // + i * 16 rows * 64 B
-    const int b_off = FOPER + fswz(frow, fk);              // + j * 16 rows * 64 B
-    bf16x8 fa[2][2], fb[2][NF];
+    const int a_off = fswz(wm * 16 * MF + frow, fk);                   // + i * 16 rows * 64 B
+    const int b_off = G::AOPER + fswz(wn * 16 * NF + frow, fk);        // + j * 16 rows * 64 B
+    bf16x8 fa[2][MF], fb[2][NF];
 
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < nk) issue(i);
     {
         const int later = min(nk, 4) - 1;
-        if (later == 3) __builtin_amdgcn_s_waitcnt(vm_only(12));
-        else if (later == 2) __builtin_amdgcn_s_waitcnt(vm_only(8));
-        else if (later == 1) __builtin_amdgcn_s_waitcnt(vm_only(4));
+        if (later == 3) __builtin_amdgcn_s_waitcnt(vm_only(3 * G::NDMA));
+        else if (later == 2) __builtin_amdgcn_s_waitcnt(vm_only(2 * G::NDMA));
+        else if (later == 1) __builtin_amdgcn_s_waitcnt(vm_only(G::NDMA));
         else __builtin_amdgcn_s_waitcnt(vm_only(0));
     }
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a_off + i * 1024);
+    for (int i = 0; i < MF; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a_off + i * 1024);
 #pragma unroll
     for (int j = 0; j < NF; ++j) fb[0][j] = *reinterpret_cast<const bf16x8*>(smem + b_off + j * 1024);
 
     int t = 0;
     for (; t + 1 < nk; t += 2) {
-        EAVQA_NARROW_STEP(0, t)
-        EAVQA_NARROW_STEP(1, t + 1)
+        EAVQA_SHAPED_STEP(0, t)
+        EAVQA_SHAPED_STEP(1, t + 1)
     }
-    if (t < nk) EAVQA_NARROW_STEP(0, t)
+    if (t < nk) EAVQA_SHAPED_STEP(0, t)
     __syncthreads();
 
     float* Cs = reinterpret_cast<float*>(smem);
+    for (int pass = 0; pass < WM / G::SP; ++pass) {
+        if (wm / G::SP == pass) {
+            const int r0 = (wm % G::SP) * 16 * MF;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
-        for (int j = 0; j < NF; ++j)
+                for (int j = 0; j < NF; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wave * 32 + i * 16 + (lane >> 4) * 4 + r;
-                const int col = j * 16 + (lane & 15);
-                Cs[row * CS_PITCH + col] = acc[i][j][r];
-            }
-    __syncthreads();
-    constexpr int TPR = 4 * NF, RPP = 256 / TPR, NPASS = (BM + RPP - 1) / RPP;
-    epilogue<bf16_t, EpiGeo<TPR, RPP, NPASS, CS_PITCH, BM>>(p, Cs, m0, n0);
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = r0 + i * 16 + (lane >> 4) * 4 + r;
+                        const int col = wn * 16 * NF + j * 16 + (lane & 15);
+                        Cs[row * G::PITCH + col] = acc[i][j][r];
+                    }
+        }
+        __syncthreads();
+        epilogue<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>>(p, Cs, m0 + pass * G::PROWS, n0);
+        if (pass + 1 < WM / G::SP) __syncthreads();
+    }
 }
-#undef EAVQA_NARROW_STEP
+#undef EAVQA_SHAPED_STEP
 
-template <int NF>
-int launch_narrow(const GemmParams& p, hipStream_t stream) {
+template <int WM, int WN, int MF, int NF>
+int launch_shaped(const GemmParams& p, hipStream_t stream) {
+    using G = TileGeo<WM, WN, MF, NF>;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_narrow_kernel<NF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                100 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_shaped_kernel<WM, WN, MF, NF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
             return EAVQA_E_LAUNCH;
         configured = true;
     }
-    const int tiles_m = p.tiles_m, tiles_n = (p.N + 16 * NF - 1) / (16 * NF);
-    int best_gx = 8, best_cost = 1 << 30;
-    const int cand[4] = {8, 4, 2, 1};
-    for (int c = 0; c < 4; ++c) {
-        const int gx = cand[c], gy = 8 / gx;
-        const int cost = ((tiles_m + gx - 1) / gx) * 128 + ((tiles_n + gy - 1) / gy) * 16 * NF;
-        if (cost < best_cost) { best_cost = cost; best_gx = gx; }
-    }
-    const int gx = best_gx, gy = 8 / gx;
-    const int per_xcd = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
-    // experiment knob (deep == 3): ask for > 80 KiB so that at most one workgroup fits a CU
-    hipLaunchKernelGGL(gemm_bf16_narrow_kernel<NF>, dim3(per_xcd * 8), dim3(256), g_deep == 3 ? 100 * 1024 : CS_BYTES, stream, p, gx, gy,
+    const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
+    const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
+    hipLaunchKernelGGL((gemm_bf16_shaped_kernel<WM, WN, MF, NF>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
                        tiles_m, tiles_n);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }
 
-// 0 = choose by shape, 1 = never, 5 / 6 = always that NF
-int g_narrow_mode = 0;
+// test / experiment knob: 0 = choose by shape, 1 = never a shaped tile, else force SHAPES[id - 2]
+int g_shape_mode = 0;
 
-// Relative time of a grid of `tiles` (bm x bn) tiles: a CU takes in operand bytes at a fixed rate (measured: K = 5120 takes
-// 50 / 51 / 54 us on 80 / 160 / 256 tiles of 128 x 128 and 103 us on 512: two co-resident workgroups share the rate of one),
-// so time ~ rounds of 256 workgroups x bytes per workgroup and K-step.
-inline float tile_cost(int tiles, int bm, int bn) { return ((tiles + 255) / 256) * float(bm + bn); }
+struct ShapeChoice { int bm, bn; int (*launch)(const GemmParams&, hipStream_t); };
+const ShapeChoice SHAPES[5] = {
+    {128, 80, launch_shaped<4, 1, 2, 5>}, {128, 96, launch_shaped<4, 1, 2, 6>},
+    {256, 128, launch_shaped<4, 2, 4, 4>}, {256, 160, launch_shaped<4, 2, 4, 5>}, {256, 192, launch_shaped<4, 2, 4, 6>},
+};
 
-// narrow tile width (0 = keep 128 x 128) for a k-contiguous bf16 GEMM
-int narrow_choice(const GemmParams& p) {
-    if (g_narrow_mode == 1) return 0;
-    if (g_narrow_mode == 5 || g_narrow_mode == 6) return g_narrow_mode;
-    int best = 0;
-    float best_cost = tile_cost(p.tiles_m * p.tiles_n, 128, 128);
-    for (int nf = 6; nf >= 5; --nf) {
-        const float c = tile_cost(p.tiles_m * ((p.N + 16 * nf - 1) / (16 * nf)), 128, 16 * nf);
-        if (c < best_cost * 0.97f) { best_cost = c; best = nf; }
-    }
-    return best;
+// Modelled time (ns, without the launch) of a grid of bm x bn tiles: the fullest XCD's workgroups per CU (co-resident
+// ones share the CU's intake rate) x (operand bytes per K-step at that rate + the tile's epilogue).  Calibrated on MI355X
+// (128 x 128: 17.8 us at K = 1280, 51.9 us at K = 5120; 256 x 128 on 240 tiles: 29 us at K = 1280).
+inline float tile_cost(const GemmParams& p, int bm, int bn) {
+    const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + bn - 1) / bn;
+    const GridPlan g = plan_grid(tiles_m, tiles_n, bm, bn);
+    const float rounds = float((g.per_xcd + 31) / 32);
+    return rounds * (1.11f * (bm + bn) * (p.K / 32) + 0.25f * bm * bn);
 }
 
 // ====================================================== bf16 big tiles ===
@@ -1088,7 +1132,7 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
 extern "C" void eavqa_debug_disable_fast_gemm(int disable) { g_disable_fast = disable != 0; }
 extern "C" void eavqa_debug_gemm_stagger(int units) {
     g_stagger = units & 0xff; g_ablate = (units >> 8) & 7; g_big_mode = (units >> 16) & 3; g_deep = (units >> 20) & 3;
-    g_narrow_mode = (units >> 24) & 7;
+    g_shape_mode = (units >> 24) & 7;
 }
 
 extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
@@ -1128,11 +1172,21 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
         if (a_kc && b_kc && !g_disable_fast && M <= 64 && (K % 32) == 0 && N >= 64) return launch_skinny(p, s);
-        if (a_kc && b_kc && !g_disable_fast && use_big(p)) return launch_big(p, s);
-        if (a_kc && b_kc && (K % FBK) == 0 && !g_disable_fast) {
-            const int nf = narrow_choice(p);
-            if (nf == 5) return launch_narrow<5>(p, s);
-            if (nf == 6) return launch_narrow<6>(p, s);
+        if (a_kc && b_kc && !g_disable_fast && (K % FBK) == 0) {
+            if (g_shape_mode >= 2 && g_shape_mode < 7) return SHAPES[g_shape_mode - 2].launch(p, s);
+            const bool big_ok = (K % GBK) == 0 && g_big_mode != 1;
+            if (big_ok && g_big_mode == 2) return launch_big(p, s);
+            // candidates in order of preference at equal cost: 128 x 128 (two workgroups per CU), 256 x 256, shaped tiles
+            float best = tile_cost(p, 128, 128);
+            int pick = -1;                                   // -1 fast, -2 big, >= 0 SHAPES[pick]
+            if (big_ok && use_big(p)) { best = fminf(best, tile_cost(p, 256, 256)); pick = -2; }
+            if (g_shape_mode != 1)
+                for (int i = 0; i < 5; ++i) {
+                    const float c = tile_cost(p, SHAPES[i].bm, SHAPES[i].bn);
+                    if (c < best * 0.95f) { best = c; pick = i; }
+                }
+            if (pick >= 0) return SHAPES[pick].launch(p, s);
+            if (pick == -2) return launch_big(p, s);
             return launch_fast(p, s);
         }
         if (a_kc && b_kc) return launch(gemm_bf16_kernel<true, true>, p, s);

@@ -43,17 +43,17 @@ ACTS = {
 
 
 # --------------------------------------------------------------------------- GEMM
-@pytest.fixture(params=["fast", "general", "big", "narrow5", "narrow6"])
+@pytest.fixture(params=["fast", "general", "big", "128x80", "128x96", "256x128", "256x160", "256x192"])
 def gemm_path(request):
     """bf16 k-contiguous GEMMs take the 128x128 LDS-DMA kernel (K % 32 == 0) or the 256x256 one (K % 64 == 0, chosen by
-    shape) or a narrow 128x80 / 128x96 one (chosen by shape); run every case through the general kernel, the 128x128
-    kernel and (forced) the 256x256 and narrow kernels."""
+    shape) or a shaped tile (128x80 ... 256x192, chosen by shape); run every case through the general kernel, the 128x128
+    kernel and (forced) the 256x256 kernel and every shaped tile."""
     from eavqa_amd import _lib
     lib = _lib.load()
     lib.eavqa_debug_disable_fast_gemm(int(request.param == "general"))
-    big = {"fast": 1, "general": 1, "big": 2, "narrow5": 1, "narrow6": 1}[request.param]
-    narrow = {"fast": 1, "general": 1, "big": 1, "narrow5": 5, "narrow6": 6}[request.param]
-    lib.eavqa_debug_gemm_stagger((big << 16) | (narrow << 24))
+    big = 2 if request.param == "big" else 1
+    shape = {"128x80": 2, "128x96": 3, "256x128": 4, "256x160": 5, "256x192": 6}.get(request.param, 1)
+    lib.eavqa_debug_gemm_stagger((big << 16) | (shape << 24))
     yield request.param
     lib.eavqa_debug_disable_fast_gemm(0)
     lib.eavqa_debug_gemm_stagger(0)

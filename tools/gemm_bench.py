@@ -36,14 +36,14 @@ def main():
     ap.add_argument("--stagger", type=int, default=0)
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation variant of the fast kernel (wrong results)")
     ap.add_argument("--big", type=int, default=0, help="0 auto, 1 never 256x256, 2 always 256x256")
-    ap.add_argument("--narrow", type=int, default=0, help="0 auto, 1 never a narrow tile, 5 / 6 always 128x80 / 128x96")
+    ap.add_argument("--shape", type=int, default=0, help="0 auto, 1 never a shaped tile, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192")
     ap.add_argument("--deep", type=int, default=0, help="8-stage ring: 0 auto, 1 never, 2 always")
     ap.add_argument("--check", action="store_true", help="compare the result with a torch matmul")
     ap.add_argument("--cold", action="store_true", help="rotate over enough copies of the weight to defeat L2 + Infinity Cache")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
     _lib.load().eavqa_debug_disable_fast_gemm(int(args.general))
-    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8) | (args.big << 16) | (args.deep << 20) | (args.narrow << 24))
+    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8) | (args.big << 16) | (args.deep << 20) | (args.shape << 24))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
     for M, N, K, what in SHAPES:
