@@ -37,6 +37,10 @@ SIGNATURES = {
     "eavqa_build_row_plan": [i32, i32, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "eavqa_copy_rows": [i32, i32, i32, i32, ptr, i64, i64, ptr, i64, i64, i64, ptr],
     "eavqa_transpose": [i32, i32, i32, ptr, i64, ptr, i64, ptr],
+    "eavqa_gemm_splitk_plan": [i32, i32, i32],
+    "eavqa_gemm_splitk": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i32, ptr],
+    "eavqa_splitk_finish": [i32, i32, i32, ptr, i32, ptr, i32, ptr, i64, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr],
+    "eavqa_layernorm_splitk": [i32, i32, i32, ptr, i64, ptr, i32, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, ptr],
     "eavqa_colsum": [i32, i32, i32, ptr, i64, ptr, i32, ptr],
     "eavqa_embed_assemble": [i32, i32, i32, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr],
     "eavqa_embed_assemble_bwd": [i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr],

@@ -415,6 +415,107 @@ int check_common(int dtype, int B, int H, int Sq, int Sk, int hd) {
     return EAVQA_OK;
 }
 
+
+// ------------------------------------------------------------ decode (Sq = 1) ---
+// One new query per sample against a cache of Sk keys: the work is reading K and V once (2 Sk hd bytes x 2 per head), so
+// the kernel is laid out for that read.  A workgroup = 4 waves = 4 neighbouring heads of one sample (their K / V slices
+// are adjacent in the [S, E] cache rows: 4 hd x 2 contiguous bytes per key); a wave gives LPK lanes to a key (16 bytes =
+// 8 head dims each) and walks 64 / LPK keys per load instruction, DEC_U instructions in flight.  Scores go to LDS, the
+// softmax runs over them in fp32, then the same walk over V with the probabilities.  Same masking rule as the tiled
+// kernels: masked scores become -FLT_MAX (a fully masked row averages all keys).
+constexpr int DEC_U = 8;
+
+template <int LPK>
+__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
+                                                          int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv, bf16_t* __restrict__ out,
+                                                          int64_t ldo, int64_t bsq, int64_t bsk, const int32_t* __restrict__ key_mask,
+                                                          int64_t ld_mask, float* __restrict__ lse, int H, int Sk, int hd, float scale) {
+    extern __shared__ float dec_sc[];                 // [4 heads][Sk]
+    constexpr int KPI = 64 / LPK;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
+    if (h >= H) return;
+    const int sub = lane / LPK, dl = lane % LPK;
+    const bool active = 8 * dl < hd;
+    float* sc = dec_sc + wave * Sk;
+    float qf[8];
+    {
+        bf16x8 t = {};
+        if (active) t = *reinterpret_cast<const bf16x8*>(q + (int64_t)b * bsq * ldq + h * hd + 8 * dl);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[e] = (float)t[e];
+    }
+    const bf16_t* kb = k + (int64_t)b * bsk * ldk + h * hd + 8 * dl;
+    const bf16_t* vb = v + (int64_t)b * bsk * ldv + h * hd + 8 * dl;
+    const int32_t* mrow = key_mask ? key_mask + (int64_t)b * ld_mask : nullptr;
+
+    for (int j0 = 0; j0 < Sk; j0 += KPI * DEC_U) {
+        bf16x8 kv[DEC_U];
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u) {
+            const int j = j0 + u * KPI + sub;
+            kv[u] = (bf16x8){};
+            if (active && j < Sk) kv[u] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)j * ldk);
+        }
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u) {
+            const int j = j0 + u * KPI + sub;
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += qf[e] * (float)kv[u][e];
+#pragma unroll
+            for (int o = LPK >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+            if (dl == 0 && j < Sk) sc[j] = (mrow && mrow[j] == 0) ? -FLT_MAX : d * scale;
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);              // this wave's LDS writes (lgkmcnt 0); sc is private to the wave
+    float mx = -FLT_MAX;
+    for (int j = lane; j < Sk; j += 64) mx = fmaxf(mx, sc[j]);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < Sk; j += 64) {
+        const float pj = __expf(sc[j] - mx);
+        sc[j] = pj;
+        sum += pj;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < Sk; j0 += KPI * DEC_U) {
+        bf16x8 vv[DEC_U];
+        float pj[DEC_U];
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u) {
+            const int j = j0 + u * KPI + sub;
+            vv[u] = (bf16x8){};
+            pj[u] = 0.f;
+            if (active && j < Sk) { vv[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv); pj[u] = sc[j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += pj[u] * (float)vv[u][e];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int off = LPK; off < 64; off <<= 1) o[e] += __shfl_xor(o[e], off, 64);
+    if (sub == 0 && active) {
+        const float inv = 1.f / sum;
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (bf16_t)(o[e] * inv);
+        *reinterpret_cast<bf16x8*>(out + (int64_t)b * bsq * ldo + h * hd + 8 * dl) = r;
+    }
+    if (lse && lane == 0) lse[(int64_t)b * H + h] = mx + __logf(sum);
+}
+
+bool decode_supported(int dtype, int Sq, int Sk, int hd, const int32_t* cu, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo) {
+    return dtype == EAVQA_BF16 && Sq == 1 && !cu && hd % 8 == 0 && hd <= 128 && Sk <= 4096 && (ldq % 8 == 0) && (ldk % 8 == 0) &&
+           (ldv % 8 == 0) && (ldo % 8 == 0);
+}
+
 }  // namespace
 
 extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,
@@ -439,6 +540,19 @@ extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int 
     p.bsk = kv_batch_rows > 0 ? kv_batch_rows : Sk;
     if (p.bsq < Sq || p.bsk < Sk) return EAVQA_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (decode_supported(dtype, Sq, Sk, hd, cu_seqlens, ldq, ldk, ldv, ldo) && !g_force_valu && eavqa_aligned16(q) && eavqa_aligned16(k) &&
+        eavqa_aligned16(v) && eavqa_aligned16(o)) {
+        const dim3 grid(B, (H + 3) / 4);
+        const size_t lds = (size_t)4 * Sk * sizeof(float);
+#define EAVQA_DEC(LPK)                                                                                                       \
+    hipLaunchKernelGGL(attn_decode_kernel<LPK>, grid, dim3(256), lds, s, reinterpret_cast<const bf16_t*>(q), ldq,              \
+                       reinterpret_cast<const bf16_t*>(k), ldk, reinterpret_cast<const bf16_t*>(v), ldv,                      \
+                       reinterpret_cast<bf16_t*>(o), ldo, p.bsq, p.bsk, key_mask, p.ld_mask, lse, H, Sk, hd, scale)
+        if (hd <= 64) EAVQA_DEC(8); else EAVQA_DEC(16);
+#undef EAVQA_DEC
+        EAVQA_LAUNCH_CHECK();
+        return EAVQA_OK;
+    }
     if (dtype == EAVQA_BF16 && eavqa_attn_mfma::supported(hd) && !g_force_valu) {
         eavqa_attn_mfma::Params m = {};
         m.q = q; m.k = k; m.v = v; m.out = o; m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo;

@@ -1,0 +1,303 @@
+// Decode-step kernels (one new token per sample, M = batch <= 64 rows): the step is a weight-streaming problem, HBM bound
+// on the 12 E^2 weights of every layer, and a chain of short dependent kernels.  Three pieces (eavqa.h):
+//
+//   eavqa_gemm_splitk      P[s][m][n] = sum_{k in slice s} A[m,k] B[n,k]        (bf16 in, fp32 partial sums out)
+//   eavqa_splitk_finish    out = act(sum_s P[s] + bias) (+ residual), columns cut into up to 3 destination segments
+//                          (q | k-cache row | v-cache row: the K/V append is the finish of the QKV projection)
+//   eavqa_layernorm_splitk x = x_in + bias + sum_s P[s];  y = LayerNorm(x)      (residual add + finish + LN in one pass)
+//
+// Why split K over workgroups: with M <= 64 every workgroup needs the whole activation slab A, and the first skinny
+// kernel (16 columns x all of K per workgroup) pulled 2 bytes of A through the CU's L1 for every byte of weights: the
+// L2 -> CU path (about 55 GB/s per CU), not HBM, set its 2.4 TB/s.  Here a workgroup owns 64 columns x one K slice: its
+// A slice is staged ONCE in LDS (LDS-DMA, swizzled 64-byte rows as in the tiled GEMMs) and shared by the four waves, each
+// of which streams its own 16 weight rows straight into VGPRs (8 loads in flight per wave).  A-bytes per weight byte:
+// 16 MF / 64 = 0.5 (MF = 2), and N / 64 x ks workgroups keep every CU loading.  The partial sums (ks x M x N fp32, 10-20 %
+// of the weight bytes) are summed in a fixed order by the consumer, so the result does not depend on scheduling.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int fswz(int row, int kc) { return row * 64 + ((kc ^ ((-(row >> 2)) & 3)) << 4); }
+
+constexpr int SK_COLS = 64;       // columns per workgroup (4 waves x 16)
+constexpr int SK_UNROLL = 8;      // weight loads in flight per wave
+
+template <int MF>
+__global__ __launch_bounds__(256) void gemm_bf16_splitk_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                               const bf16_t* __restrict__ B, int64_t ldb,
+                                                               float* __restrict__ P, int M, int N, int KS) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 16 * MF * 64;                      // bytes of one [16 MF rows][32 k] A tile
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * SK_COLS, slice = blockIdx.y, k0 = slice * KS;
+    const int nsteps = KS >> 5;
+
+    // ---- stage the A slice: chunk c -> tile c / (64 MF), row (c % (64 MF)) >> 2, physical slot c & 3
+    const int total = nsteps * 64 * MF;
+    for (int base = wave * 64; base < total; base += 256) {
+        const int c = base + lane;
+        if (c < total) {
+            const int t = c / (64 * MF), within = c % (64 * MF);
+            const int row = within >> 2, pc = within & 3;
+            const bf16_t* src = A + (int64_t)min(row, M - 1) * lda + k0 + t * 32 + ((pc ^ ((-(row >> 2)) & 3)) << 3);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + base * 16), 16, 0, 0);
+        }
+    }
+
+    // ---- this wave's 16 weight rows
+    const int x = lane & 15, g = lane >> 4;
+    const bf16_t* bp = B + (int64_t)min(n0 + wave * 16 + x, N - 1) * ldb + k0 + 8 * g;
+    f32x4 acc[MF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int a_off = fswz(x, g);
+
+    bf16x8 bf[SK_UNROLL];
+#pragma unroll
+    for (int u = 0; u < SK_UNROLL; ++u)
+        bf[u] = *reinterpret_cast<const bf16x8*>(bp + 32 * min(u, nsteps - 1));
+    __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);     // vmcnt(0): A slice (and the first weights) have landed
+    __syncthreads();
+
+    for (int s0 = 0; s0 < nsteps; s0 += SK_UNROLL) {
+        bf16x8 cur[SK_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SK_UNROLL; ++u) cur[u] = bf[u];
+        if (s0 + SK_UNROLL < nsteps) {
+#pragma unroll
+            for (int u = 0; u < SK_UNROLL; ++u)
+                bf[u] = *reinterpret_cast<const bf16x8*>(bp + 32 * min(s0 + SK_UNROLL + u, nsteps - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < SK_UNROLL; ++u) {
+            if (s0 + u < nsteps) {
+                const char* tile = smem + (s0 + u) * TILE;
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(tile + a_off + i * 1024);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, cur[u], acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    const int n = n0 + wave * 16 + x;
+    if (n < N) {
+        float* out = P + (int64_t)slice * M * N + n;
+#pragma unroll
+        for (int i = 0; i < MF; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * i + 4 * g + r;
+                if (m < M) out[(int64_t)m * N] = acc[i][r];
+            }
+    }
+}
+
+struct FinishSeg { void* dst; int64_t ld; };
+
+// out[m, n] = act(sum_s P[s][m][n] + bias[n]) (+ residual[m, n]); 4 columns per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(int M, int N, const float* __restrict__ P, int ks, const float* __restrict__ bias,
+                                                            int act, const float* __restrict__ residual, int64_t ldr, int out_f32,
+                                                            int seg_cols, FinishSeg s0, FinishSeg s1, FinishSeg s2) {
+    const int nq = N >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * nq) return;
+    const int m = idx / nq, n = (idx % nq) * 4;
+    float4 v = *reinterpret_cast<const float4*>(P + (int64_t)m * N + n);
+    for (int s = 1; s < ks; ++s) {
+        const float4 t = *reinterpret_cast<const float4*>(P + ((int64_t)s * M + m) * N + n);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+    v.x = act_fwd(act, v.x); v.y = act_fwd(act, v.y); v.z = act_fwd(act, v.z); v.w = act_fwd(act, v.w);
+    if (residual) {
+        const float4 r = *reinterpret_cast<const float4*>(residual + (int64_t)m * ldr + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    const int seg = n / seg_cols, nl = n - seg * seg_cols;
+    const FinishSeg d = seg == 0 ? s0 : (seg == 1 ? s1 : s2);
+    if (out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(d.dst) + (int64_t)m * d.ld + nl) = v;
+    else elem<T>::st4(reinterpret_cast<T*>(d.dst) + (int64_t)m * d.ld + nl, v);
+}
+
+// one 256-thread workgroup per row (a decode step has at most 64 rows: parallelism must come from inside the row), the
+// partial-sum loads of four slices in flight at once: x = x_in + bias + sum_s P[s]; y = LN(x) * gamma + beta
+__device__ __forceinline__ float block_sum4(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_splitk_kernel(int rows, int cols, const float* __restrict__ x_in, int64_t ldx,
+                                                        const float* __restrict__ P, int ks, const float* __restrict__ bias,
+                                                        float* __restrict__ x_out, int64_t ldxo, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, T* __restrict__ y, int64_t ldy) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int nv = cols >> 2;
+    float4 v[NV], gm[NV], bt[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const float4*>(x_in + (int64_t)row * ldx + 4 * c);
+            gm[i] = *reinterpret_cast<const float4*>(gamma + 4 * c);
+            bt[i] = *reinterpret_cast<const float4*>(beta + 4 * c);
+            if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c); v[i].x += b.x; v[i].y += b.y; v[i].z += b.z; v[i].w += b.w; }
+        }
+    }
+    const int64_t slice = (int64_t)rows * cols;
+    const float* prow = P + (int64_t)row * cols;
+    int sl = 0;
+    for (; sl + 4 <= ks; sl += 4) {
+        float4 t[4][NV];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = tid + 256 * i;
+                t[u][i] = c < nv ? *reinterpret_cast<const float4*>(prow + (sl + u) * slice + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)          // slices are added in index order: the sum does not depend on scheduling
+#pragma unroll
+            for (int i = 0; i < NV; ++i) { v[i].x += t[u][i].x; v[i].y += t[u][i].y; v[i].z += t[u][i].z; v[i].w += t[u][i].w; }
+    }
+    for (; sl < ks; ++sl) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = tid + 256 * i;
+            if (c < nv) {
+                const float4 t = *reinterpret_cast<const float4*>(prow + sl * slice + 4 * c);
+                v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+            }
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nv) {
+            if (x_out) *reinterpret_cast<float4*>(x_out + (int64_t)row * ldxo + 4 * c) = v[i];
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    const float mu = block_sum4(s, red) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nv) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rs = rsqrtf(block_sum4(q, red) / (float)cols + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = tid + 256 * i;
+        if (c < nv) {
+            float4 o;
+            o.x = (v[i].x - mu) * rs * gm[i].x + bt[i].x;
+            o.y = (v[i].y - mu) * rs * gm[i].y + bt[i].y;
+            o.z = (v[i].z - mu) * rs * gm[i].z + bt[i].z;
+            o.w = (v[i].w - mu) * rs * gm[i].w + bt[i].w;
+            elem<T>::st4(y + (int64_t)row * ldy + 4 * c, o);
+        }
+    }
+}
+
+inline int splitk_mf(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
+
+}  // namespace
+
+extern "C" int eavqa_gemm_splitk_plan(int M, int N, int K) {
+    if (M <= 0 || M > 64 || N <= 0 || K <= 0 || K % 32) return 0;
+    const int mf = splitk_mf(M), groups = (N + SK_COLS - 1) / SK_COLS;
+    int best = 0;
+    for (int ks = 1; ks <= 16; ++ks) {
+        if (K % (32 * ks)) continue;
+        const int lds = (K / ks) * mf * 32;              // bytes of the staged A slice
+        if (lds > 64 * 1024) continue;                   // two workgroups per CU
+        best = ks;
+        if (groups * ks >= 320) break;                   // enough workgroups to keep every CU streaming
+    }
+    return best;
+}
+
+extern "C" int eavqa_gemm_splitk(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                 float* partials, int ks, void* stream) {
+    if (dtype != EAVQA_BF16) return EAVQA_E_DTYPE;
+    if (!A || !B || !partials || M <= 0 || M > 64 || N <= 0 || K <= 0 || ks <= 0) return EAVQA_E_ARG;
+    if (K % (32 * ks) || lda < K || ldb < K) return EAVQA_E_SHAPE;
+    if (lda % 8 || ldb % 8 || !eavqa_aligned16(A) || !eavqa_aligned16(B)) return EAVQA_E_ALIGN;
+    const int mf = splitk_mf(M), KS = K / ks;
+    const int lds = KS * mf * 32;
+    if (lds > 150 * 1024) return EAVQA_E_SHAPE;
+    typedef void (*kernel_t)(const bf16_t*, int64_t, const bf16_t*, int64_t, float*, int, int, int);
+    const kernel_t kernel = mf == 1 ? gemm_bf16_splitk_kernel<1> : (mf == 2 ? gemm_bf16_splitk_kernel<2> : gemm_bf16_splitk_kernel<4>);
+    static bool configured[3] = {false, false, false};
+    const int slot = mf == 1 ? 0 : (mf == 2 ? 1 : 2);
+    if (!configured[slot]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return EAVQA_E_LAUNCH;
+        configured[slot] = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3((N + SK_COLS - 1) / SK_COLS, ks), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(B), ldb, partials, M, N, KS);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_splitk_finish(int dtype, int M, int N, const float* partials, int ks, const float* bias, int act,
+                                   const float* residual, int64_t ld_residual, int out_f32, int n_seg,
+                                   void* out0, int64_t ld0, void* out1, int64_t ld1, void* out2, int64_t ld2, void* stream) {
+    if (dtype != EAVQA_BF16 && dtype != EAVQA_F32) return EAVQA_E_DTYPE;
+    if (!partials || !out0 || M <= 0 || N <= 0 || ks <= 0 || n_seg < 1 || n_seg > 3) return EAVQA_E_ARG;
+    if ((n_seg > 1 && !out1) || (n_seg > 2 && !out2)) return EAVQA_E_ARG;
+    if (N % (4 * n_seg) || ld0 % 4 || (n_seg > 1 && ld1 % 4) || (n_seg > 2 && ld2 % 4) || (residual && ld_residual % 4)) return EAVQA_E_SHAPE;
+    if (act < EAVQA_ACT_NONE || act > EAVQA_ACT_QUICK_GELU) return EAVQA_E_DTYPE;
+    const int seg_cols = N / n_seg;
+    const FinishSeg s0{out0, ld0}, s1{out1, ld1}, s2{out2, ld2};
+    const int threads = M * (N / 4);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_BF16)
+        hipLaunchKernelGGL(splitk_finish_kernel<bf16_t>, dim3((threads + 255) / 256), dim3(256), 0, s, M, N, partials, ks, bias, act,
+                           residual, ld_residual, out_f32, seg_cols, s0, s1, s2);
+    else
+        hipLaunchKernelGGL(splitk_finish_kernel<float>, dim3((threads + 255) / 256), dim3(256), 0, s, M, N, partials, ks, bias, act,
+                           residual, ld_residual, 1, seg_cols, s0, s1, s2);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,
+                                      const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
+                                      float eps, void* y, int64_t ldy, void* stream) {
+    if (dtype != EAVQA_BF16 && dtype != EAVQA_F32) return EAVQA_E_DTYPE;
+    if (!x_in || !gamma || !beta || !y || rows <= 0 || cols <= 0 || ks < 0 || (ks > 0 && !partials)) return EAVQA_E_ARG;
+    if (cols % 4 || cols > 64 * 4 * 16) return EAVQA_E_SHAPE;
+    if (ldx % 4 || ldy % 4 || (x_out && ld_out % 4)) return EAVQA_E_ALIGN;
+    const int nv = (cols / 4 + 255) / 256;
+    const dim3 grid(rows), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define EAVQA_LNS(T, NV)                                                                                                    \
+    hipLaunchKernelGGL((ln_splitk_kernel<T, NV>), grid, block, 0, s, rows, cols, x_in, ldx, partials, ks, bias, x_out, ld_out, \
+                       gamma, beta, eps, reinterpret_cast<T*>(y), ldy)
+    if (dtype == EAVQA_BF16) {
+        if (nv <= 1) EAVQA_LNS(bf16_t, 1); else if (nv <= 2) EAVQA_LNS(bf16_t, 2); else EAVQA_LNS(bf16_t, 4);
+    } else {
+        if (nv <= 1) EAVQA_LNS(float, 1); else if (nv <= 2) EAVQA_LNS(float, 2); else EAVQA_LNS(float, 4);
+    }
+#undef EAVQA_LNS
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}

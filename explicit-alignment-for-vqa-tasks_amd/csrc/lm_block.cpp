@@ -9,6 +9,23 @@
 
 namespace {
 inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
+
+// decode fast path: one new position per sample, bf16, at most 64 samples, every GEMM shape plannable
+struct DecodePlan { int ks_qkv, ks_o, ks_fc1, ks_fc2; bool ok; size_t part_bytes; };
+inline DecodePlan plan_decode(int dtype, int rows, int Sq, int E, int F) {
+    DecodePlan d{0, 0, 0, 0, false, 0};
+    if (dtype != EAVQA_BF16 || Sq != 1 || rows > 64 || E % 4 || F % 4) return d;
+    d.ks_qkv = eavqa_gemm_splitk_plan(rows, 3 * E, E);
+    d.ks_o = eavqa_gemm_splitk_plan(rows, E, E);
+    d.ks_fc1 = eavqa_gemm_splitk_plan(rows, F, E);
+    d.ks_fc2 = eavqa_gemm_splitk_plan(rows, E, F);
+    d.ok = d.ks_qkv > 0 && d.ks_o > 0 && d.ks_fc1 > 0 && d.ks_fc2 > 0;
+    size_t a = (size_t)d.ks_qkv * rows * 3 * E, b = (size_t)d.ks_o * rows * E, c = (size_t)d.ks_fc1 * rows * F;
+    size_t m = a > b ? a : b;
+    m = m > c ? m : c;
+    d.part_bytes = align_up(m * 4) + align_up((size_t)d.ks_fc2 * rows * E * 4);   // scratch partials + the FFN-down partials that
+    return d;                                                                       // live until the next layer's LayerNorm
+}
 }
 
 extern "C" int64_t eavqa_lm_block_workspace_bytes(int dtype, int rows, int E, int F) {
@@ -19,6 +36,8 @@ extern "C" int64_t eavqa_lm_block_workspace_bytes(int dtype, int rows, int E, in
     b += align_up((size_t)rows * E * es);        // attention output
     b += align_up((size_t)rows * E * 4);         // x1 (fp32 residual stream after attention)
     b += align_up((size_t)rows * F * es);        // FFN activation
+    const DecodePlan d = plan_decode(dtype, rows, 1, E, F);      // rows <= 64: may be a decode step (Sq = 1)
+    if (d.ok) b += d.part_bytes;
     return (int64_t)b;
 }
 
@@ -35,9 +54,38 @@ extern "C" int eavqa_lm_block_forward(int dtype, int n_layer, const eavqa_lm_lay
     char* qkv = w;          w += align_up((size_t)rows * 3 * E * es);
     void* ctx = w;          w += align_up((size_t)rows * E * es);
     float* x1 = reinterpret_cast<float*>(w); w += align_up((size_t)rows * E * 4);
-    void* f = w;
+    void* f = w;            w += align_up((size_t)rows * F * es);
     const float scale = 1.0f / sqrtf((float)hd);
     int rc;
+    const DecodePlan d = plan_decode(dtype, rows, Sq, E, F);
+    if (d.ok) {
+        // ---- decode step: split-K weight streaming; every GEMM leaves fp32 partial sums that its consumer adds up
+        float* part = reinterpret_cast<float*>(w);
+        float* part2 = reinterpret_cast<float*>(w + (d.part_bytes - align_up((size_t)d.ks_fc2 * rows * E * 4)));
+        for (int l = 0; l < n_layer; ++l) {
+            const eavqa_lm_layer_t& L = layers[l];
+            // x = x1 + b_fc2 + sum(FFN-down partials of the previous layer); a = LN1(x)
+            if (l == 0) rc = eavqa_layernorm_splitk(dtype, rows, E, x, E, nullptr, 0, nullptr, nullptr, 0, L.ln1_g, L.ln1_b, eps, a, E, stream);
+            else rc = eavqa_layernorm_splitk(dtype, rows, E, x1, E, part2, d.ks_fc2, layers[l - 1].b_fc2, x, E, L.ln1_g, L.ln1_b, eps, a, E, stream);
+            if (rc) return rc;
+            if ((rc = eavqa_gemm_splitk(dtype, rows, 3 * E, E, a, E, L.w_qkv, E, part, d.ks_qkv, stream))) return rc;
+            // q -> qkv[:, :E]; k, v -> cache rows (sample m at row m * S_max + row0)
+            if ((rc = eavqa_splitk_finish(dtype, rows, 3 * E, part, d.ks_qkv, L.b_qkv, EAVQA_ACT_NONE, nullptr, 0, 0, 3, qkv, 3 * E,
+                                          static_cast<char*>(L.k_cache) + (size_t)row0 * E * es, (int64_t)S_max * E,
+                                          static_cast<char*>(L.v_cache) + (size_t)row0 * E * es, (int64_t)S_max * E, stream))) return rc;
+            if ((rc = eavqa_attention_fwd(dtype, B, H, Sq, Sk, hd, qkv, 3 * E, L.k_cache, E, L.v_cache, E, ctx, E, Sq, S_max, key_mask, ld_mask,
+                                          nullptr, 1, scale, nullptr, stream))) return rc;
+            if ((rc = eavqa_gemm_splitk(dtype, rows, E, E, ctx, E, L.w_o, E, part, d.ks_o, stream))) return rc;
+            // x1 = x + b_o + sum(partials); a = LN2(x1)
+            if ((rc = eavqa_layernorm_splitk(dtype, rows, E, x, E, part, d.ks_o, L.b_o, x1, E, L.ln2_g, L.ln2_b, eps, a, E, stream))) return rc;
+            if ((rc = eavqa_gemm_splitk(dtype, rows, F, E, a, E, L.w_fc1, E, part, d.ks_fc1, stream))) return rc;
+            if ((rc = eavqa_splitk_finish(dtype, rows, F, part, d.ks_fc1, L.b_fc1, act, nullptr, 0, 0, 1, f, F, nullptr, 0, nullptr, 0, stream))) return rc;
+            if ((rc = eavqa_gemm_splitk(dtype, rows, E, F, f, F, L.w_fc2, F, part2, d.ks_fc2, stream))) return rc;
+        }
+        // x = x1 + b_fc2 + sum(last FFN-down partials)
+        return eavqa_splitk_finish(dtype, rows, E, part2, d.ks_fc2, layers[n_layer - 1].b_fc2, EAVQA_ACT_NONE, x1, E, 1, 1, x, E, nullptr, 0,
+                                   nullptr, 0, stream);
+    }
     for (int l = 0; l < n_layer; ++l) {
         const eavqa_lm_layer_t& L = layers[l];
         if ((rc = eavqa_layernorm_fwd(dtype, 1, rows, E, x, E, L.ln1_g, L.ln1_b, eps, a, E, nullptr, nullptr, stream))) return rc;

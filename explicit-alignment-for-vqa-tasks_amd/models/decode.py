@@ -63,7 +63,9 @@ class _KVCache:
                 setattr(t, name, getattr(L, name).data_ptr())
             t.k_cache, t.v_cache = self.k[i].data_ptr(), self.v[i].data_ptr()
         lib = _lib.load()
-        self.ws_bytes = int(lib.eavqa_lm_block_workspace_bytes(ops.dtype_id(lm.dtype), max_rows, E, F))
+        # prefill (max_rows = B * S0 rows) and decode steps (B rows; their split-K partial sums) share one workspace
+        self.ws_bytes = max(int(lib.eavqa_lm_block_workspace_bytes(ops.dtype_id(lm.dtype), max_rows, E, F)),
+                            int(lib.eavqa_lm_block_workspace_bytes(ops.dtype_id(lm.dtype), B, E, F)))
         self.ws = torch.empty(self.ws_bytes, device=lm.device, dtype=torch.uint8)
 
 

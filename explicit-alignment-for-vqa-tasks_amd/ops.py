@@ -289,3 +289,35 @@ def transpose(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     y = out if out is not None else torch.empty((cols, rows), device=x.device, dtype=x.dtype)
     call("eavqa_transpose", dtype_id(x.dtype), rows, cols, _p(x), _ld(x), _p(y), _ld(y), _stream())
     return y
+
+
+def gemm_splitk(a: Tensor, b: Tensor, ks: Optional[int] = None) -> Tensor:
+    """fp32 partial sums [ks, M, N] of a [M,K] @ b [N,K]^T (bf16, M <= 64): the decode-step weight-streaming GEMM."""
+    M, K = a.shape
+    N = b.shape[0]
+    if ks is None:
+        ks = int(_lib.load().eavqa_gemm_splitk_plan(M, N, K))
+        if ks <= 0:
+            raise _lib.EavqaError(f"eavqa_gemm_splitk: unsupported shape M={M} N={N} K={K}")
+    part = torch.empty((ks, M, N), device=a.device, dtype=torch.float32)
+    call("eavqa_gemm_splitk", dtype_id(a.dtype), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(part), ks, _stream())
+    return part
+
+
+def splitk_finish(part: Tensor, outs, bias: Optional[Tensor] = None, act: str = "none", residual: Optional[Tensor] = None) -> None:
+    """outs: 1..3 2-D tensors (row stride = stride(0)), each receiving N / len(outs) columns of act(sum(part) + bias) (+ residual)."""
+    ks, M, N = part.shape
+    o = list(outs) + [None] * (3 - len(outs))
+    call("eavqa_splitk_finish", dtype_id(outs[0].dtype), M, N, _p(part), ks, _p(bias),
+         _lib.ACT[act], _p(residual), residual.stride(0) if residual is not None else 0, int(outs[0].dtype == torch.float32), len(outs),
+         _p(o[0]), o[0].stride(0), _p(o[1]), o[1].stride(0) if o[1] is not None else 0, _p(o[2]), o[2].stride(0) if o[2] is not None else 0,
+         _stream())
+
+
+def layernorm_splitk(x_in: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_dtype, part: Optional[Tensor] = None,
+                     bias: Optional[Tensor] = None, x_out: Optional[Tensor] = None) -> Tensor:
+    rows, cols = x_in.shape
+    y = torch.empty((rows, cols), device=x_in.device, dtype=out_dtype)
+    call("eavqa_layernorm_splitk", dtype_id(out_dtype), rows, cols, _p(x_in), _ld(x_in), _p(part), 0 if part is None else part.shape[0],
+         _p(bias), _p(x_out), _ld(x_out) if x_out is not None else 0, _p(gamma), _p(beta), float(eps), _p(y), _ld(y), _stream())
+    return y

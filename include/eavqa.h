@@ -259,6 +259,26 @@ int eavqa_lm_block_forward(int dtype, int n_layer, const eavqa_lm_layer_t* layer
                            int B, int Sq, int row0, int S_max, float* x, const int32_t* key_mask, int64_t ld_mask,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- decode-step primitives (M = batch <= 64 new tokens; replaces the eager per-step loop of
+ * `_generate_from_embeddings`, src/models/clipcap.py:414-419, once a KV cache exists) --------------------------------
+ * eavqa_gemm_splitk: bf16 A [M,K] x B [N,K]^T, K cut into `ks` slices over workgroups; fp32 partial sums
+ * partials[s][m][n] (ld = N, s-major) - no epilogue, the consumer sums the slices in order.  `ks` must divide K / 32;
+ * eavqa_gemm_splitk_plan returns the recommended ks (0 if the shape is not supported). */
+int eavqa_gemm_splitk_plan(int M, int N, int K);
+int eavqa_gemm_splitk(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                      float* partials, int ks, void* stream);
+/* out[m, n] = act(sum_s partials[s][m][n] + bias[n]) (+ residual[m, n]); the N columns are cut into n_seg (1..3) equal
+ * segments, segment j written to out_j + m * ld_j (storage `dtype`, or fp32 when out_f32).  With n_seg = 3 and
+ * out1 / out2 pointing at the cache rows this is "add the QKV bias, emit q and append k, v" in one pass. */
+int eavqa_splitk_finish(int dtype, int M, int N, const float* partials, int ks, const float* bias, int act,
+                        const float* residual, int64_t ld_residual, int out_f32, int n_seg,
+                        void* out0, int64_t ld0, void* out1, int64_t ld1, void* out2, int64_t ld2, void* stream);
+/* x = x_in + bias + sum_s partials[s] (written to x_out when non-NULL); y = LayerNorm(x) * gamma + beta in `dtype`.
+ * ks = 0: plain LayerNorm of x_in. */
+int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,
+                           const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
+                           float eps, void* y, int64_t ldy, void* stream);
+
 /* float32 -> `dtype` elementwise copy with row strides (casts the residual stream / pooled rows). */
 int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream);
 

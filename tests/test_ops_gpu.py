@@ -277,6 +277,32 @@ def test_attention_kv_cache_batch_stride(ops):
     assert (o.cpu().view(B, 1, H, hd) - ref.float()).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,Sk,hd,masked", [(3, 5, 157, 80, True), (2, 8, 300, 128, False), (2, 4, 40, 64, True), (1, 3, 7, 32, False),
+                                              (32, 32, 160, 80, True)])
+def test_attention_decode_step(ops, B, H, Sk, hd, masked):
+    """Sq = 1 in bf16 takes the decode kernel (4 heads per workgroup, K/V streamed once): cache with a batch stride, ragged
+    masks, H not a multiple of 4."""
+    E, Smax = H * hd, Sk + 9
+    ck, cv = rnd(B, Smax, E, dtype=torch.bfloat16, seed=1), rnd(B, Smax, E, dtype=torch.bfloat16, seed=2)
+    q = rnd(B, E, dtype=torch.bfloat16, seed=3)
+    km = None
+    if masked:
+        lens = torch.tensor([max(1, Sk - 5 * i) for i in range(B)])
+        km = torch.zeros(B, Smax, dtype=torch.int32)
+        km[:, :Sk] = (torch.arange(Sk)[None] < lens[:, None]).int()
+        km[:, Sk - 1] = 1            # the new token itself is always visible
+    o, lse = ops.attention_fwd(q.to(DEV), ck.view(B * Smax, E).to(DEV), cv.view(B * Smax, E).to(DEV), B, H, 1, Sk, hd,
+                               key_mask=km.to(DEV) if masked else None, ld_mask=Smax if masked else 0, causal=True, scale=hd ** -0.5,
+                               kv_batch_rows=Smax, save_lse=True)
+    kk, vv = ck.double()[:, :Sk].reshape(B, Sk, H, hd), cv.double()[:, :Sk].reshape(B, Sk, H, hd)
+    ref = attn_ref(q.double().view(B, 1, H, hd), kk, vv, km[:, :Sk] if masked else None, True, hd ** -0.5)
+    assert (o.float().cpu().view(B, 1, H, hd) - ref.float()).abs().max().item() <= 2e-2
+    s = torch.einsum("bhd,bjhd->bhj", q.double().view(B, H, hd), kk) * hd ** -0.5
+    if masked:
+        s = torch.where(km[:, None, :Sk] != 0, s, torch.full_like(s, torch.finfo(torch.float32).min))
+    assert (lse.cpu().view(B, H) - torch.logsumexp(s, -1).float()).abs().max().item() <= 1e-3
+
+
 # --------------------------------------------------------------------------- sequence assembly (bit-exact)
 @pytest.mark.parametrize("pos_mode", [0, 1])
 def test_build_prefix_rows_exact(ops, pos_mode):
@@ -522,3 +548,51 @@ def test_cross_entropy_with_row_labels(ops):
 def test_transpose(ops, dtype, rows, cols):
     x = rnd(rows, cols, dtype=dtype, seed=1).to(DEV)
     assert torch.equal(ops.transpose(x).cpu(), x.cpu().T)
+
+
+# --------------------------------------------------------------------------- decode-step primitives
+@pytest.mark.parametrize("M,N,K", [(32, 7680, 2560), (32, 2560, 10240), (1, 64, 32), (17, 200, 96), (64, 12800, 512), (5, 50272 // 8, 768)])
+def test_gemm_splitk_and_finish(ops, M, N, K):
+    a = rnd(M, K, dtype=torch.bfloat16, seed=1, scale=0.5)
+    b = rnd(N, K, dtype=torch.bfloat16, seed=2, scale=0.5)
+    ref = a.double() @ b.double().T
+    part = ops.gemm_splitk(a.to(DEV), b.to(DEV))
+    assert part.shape[1:] == (M, N)
+    got = part.double().sum(0).cpu()
+    assert (got - ref).abs().max().item() <= 1e-3 * math.sqrt(K)
+    if N % 12 == 0:
+        bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+        # three bf16 segments with different row strides (q buffer + two "cache" destinations)
+        o0 = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)[:, :N // 3]
+        o1 = torch.zeros(M, 2 * (N // 3), dtype=torch.bfloat16, device=DEV)[:, :N // 3]
+        o2 = torch.zeros(M, N // 3, dtype=torch.bfloat16, device=DEV)
+        ops.splitk_finish(part, [o0, o1, o2], bias=bias.to(DEV), act="relu")
+        want = torch.relu(ref.float() + bias)
+        cat = torch.cat([o0, o1, o2], 1).float().cpu()
+        assert (cat - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+        x = torch.empty(M, N, device=DEV)
+        ops.splitk_finish(part, [x], bias=bias.to(DEV), residual=res.to(DEV))
+        assert (x.cpu() - (ref.float() + bias + res)).abs().max().item() <= 1e-3 * math.sqrt(K)
+
+
+def test_gemm_splitk_is_deterministic(ops):
+    a = rnd(32, 2560, dtype=torch.bfloat16, seed=1).to(DEV)
+    b = rnd(2560, 2560, dtype=torch.bfloat16, seed=2).to(DEV)
+    p0 = ops.gemm_splitk(a, b)
+    for _ in range(3):
+        assert torch.equal(ops.gemm_splitk(a, b), p0)
+
+
+@pytest.mark.parametrize("rows,cols,ks", [(32, 2560, 8), (3, 768, 0), (64, 4096, 2), (7, 136, 3)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_splitk(ops, dtype, rows, cols, ks):
+    x = rnd(rows, cols, seed=1)
+    g, b, bias = rnd(cols, seed=2) + 1.0, rnd(cols, seed=3), rnd(cols, seed=4)
+    part = rnd(ks, rows, cols, seed=5) if ks else None
+    xs = x + (bias + part.sum(0) if ks else 0.0)
+    want = torch.nn.functional.layer_norm(xs, (cols,), g, b, 1e-5)
+    xo = torch.empty(rows, cols, device=DEV)
+    y = ops.layernorm_splitk(x.to(DEV), g.to(DEV), b.to(DEV), 1e-5, dtype, part=part.to(DEV) if ks else None,
+                             bias=bias.to(DEV) if ks else None, x_out=xo)
+    assert (xo.cpu() - xs).abs().max().item() <= 1e-5
+    assert (y.float().cpu() - want).abs().max().item() <= tol(dtype, 1.0) * max(1.0, want.abs().max().item())
