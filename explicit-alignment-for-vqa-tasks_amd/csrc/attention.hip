@@ -423,7 +423,7 @@ int check_common(int dtype, int B, int H, int Sq, int Sk, int hd) {
 // 8 head dims each) and walks 64 / LPK keys per load instruction, DEC_U instructions in flight.  Scores go to LDS, the
 // softmax runs over them in fp32, then the same walk over V with the probabilities.  Same masking rule as the tiled
 // kernels: masked scores become -FLT_MAX (a fully masked row averages all keys).
-constexpr int DEC_U = 8;
+constexpr int DEC_U = 32;     // 16 x 1 KiB per wave in flight: the walk is latency bound below that (4 waves per CU)
 
 template <int LPK>
 __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
@@ -468,7 +468,14 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
             if (dl == 0 && j < Sk) sc[j] = (mrow && mrow[j] == 0) ? -FLT_MAX : d * scale;
         }
     }
-    __builtin_amdgcn_s_waitcnt(0xC07F);              // this wave's LDS writes (lgkmcnt 0); sc is private to the wave
+    // the first batch of V does not depend on the scores: fetch it under the softmax
+    bf16x8 v0[DEC_U];
+#pragma unroll
+    for (int u = 0; u < DEC_U; ++u) {
+        const int j = u * KPI + sub;
+        v0[u] = (bf16x8){};
+        if (active && j < Sk) v0[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
+    }
     float mx = -FLT_MAX;
     for (int j = lane; j < Sk; j += 64) mx = fmaxf(mx, sc[j]);
     mx = wave_max(mx);
@@ -488,9 +495,12 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
             const int j = j0 + u * KPI + sub;
-            vv[u] = (bf16x8){};
-            pj[u] = 0.f;
-            if (active && j < Sk) { vv[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv); pj[u] = sc[j]; }
+            if (j0 == 0) vv[u] = v0[u];
+            else {
+                vv[u] = (bf16x8){};
+                if (active && j < Sk) vv[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
+            }
+            pj[u] = (active && j < Sk) ? sc[j] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u)

@@ -322,9 +322,60 @@ def formatter_golden():
     print(f"wrote formatter.json: {len(out['cases'])} cases")
 
 
+def vqa_eval_golden():
+    """Outputs of the reference ``VQAEval`` (src/utils/vqaEval.py; pure ``re`` + ``sys``, imported as is): the two
+    normalisers on every key of its contraction table and on a set of answer strings, and ``evaluate()`` on a synthetic
+    annotation set through a minimal stand-in for the ``VQA`` helper (only ``.qa`` and ``getQuesIds`` are touched)."""
+    import copy
+    import json
+    import random
+    sys.path.insert(0, "/root/reference/src/utils")
+    import vqaEval
+
+    class Helper:
+        def __init__(self, qa):
+            self.qa = qa
+
+        def getQuesIds(self):
+            return list(self.qa.keys())
+
+    ev = vqaEval.VQAEval(Helper({}), Helper({}), n=2)
+    strings = sorted(ev.contractions.keys()) + [
+        "Two dogs, and a cat!", "the man's hat is red.", "1,000 people", "3.5 meters.", "it's 10 o'clock", "yes", "No.", "A  frisbee",
+        "dont know", "they're playing (tennis)", "on the table; near the window", "U.S.A.", "half-full", "what?!", "none", "ten", "0.5",
+        "e.g. this / that", "[bracket]", "semi;colon", "a_b", "x > y", "email@host", "`tick`", "tab\tsep", "new\nline", " the ",
+        "An apple a day", "Im sure youve seen it", "somebody'd", "let's go", "she's here", "wouldn'tve", "...", "1.2.3", "v1.",
+        "." * 40 + "x", "a, b", "a ,b", "mid,dle", "12,5", "question?", "two  three four five six seven eight nine zero one",
+    ]
+    cases = [dict(text=t, punctuation=ev.processPunctuation(t), digit_article=ev.processDigitArticle(t),
+                  both=ev.processDigitArticle(ev.processPunctuation(t))) for t in strings]
+    rng = random.Random(2021)
+    pool = ["yes", "no", "2", "two", "red", "the red one", "Red.", "a frisbee", "frisbee", "dont know", "don't know", "1,000", "tennis",
+            "playing tennis", "white and black", "black and white", "on table", "on the table", "3", "three", "0", "none", "blue", "U.S."]
+    qa, res = {}, {}
+    for qid in range(60):
+        k = rng.choice([1, 2, 3, 4])
+        choices = rng.sample(pool, k)
+        answers = [dict(answer=rng.choice(choices), answer_confidence="yes", answer_id=i + 1) for i in range(10)]
+        qa[qid] = dict(question_id=qid, question_type=rng.choice(["what color", "is the", "how many"]),
+                       answer_type=rng.choice(["yes/no", "number", "other"]), answers=answers)
+        res[qid] = dict(question_id=qid, answer=rng.choice(choices + pool[:3]) + rng.choice(["", ".", " ", "\n"]))
+    ev = vqaEval.VQAEval(Helper(copy.deepcopy(qa)), Helper(copy.deepcopy(res)), n=2)
+    ev.evaluate()
+    out = dict(cases=cases, annotations=qa, results=res, accuracy=ev.accuracy,
+               evalQA={str(k): v for k, v in ev.evalQA.items()})
+    with open(os.path.join(HERE, "vqa_eval.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(f"wrote vqa_eval.json: {len(cases)} strings, {len(qa)} questions, overall {ev.accuracy['overall']}")
+
+
 if __name__ == "__main__":
+    if "--vqa-eval-only" in sys.argv:
+        vqa_eval_golden()
+        sys.exit(0)
     if "--formatter-only" in sys.argv:
         formatter_golden()
     else:
         main()
         formatter_golden()
+        vqa_eval_golden()
