@@ -417,27 +417,34 @@ int check_common(int dtype, int B, int H, int Sq, int Sk, int hd) {
 
 
 // ------------------------------------------------------------ decode (Sq = 1) ---
-// One new query per sample against a cache of Sk keys: the work is reading K and V once (2 Sk hd bytes x 2 per head), so
-// the kernel is laid out for that read.  A workgroup = 4 waves = 4 neighbouring heads of one sample (their K / V slices
-// are adjacent in the [S, E] cache rows: 4 hd x 2 contiguous bytes per key); a wave gives LPK lanes to a key (16 bytes =
-// 8 head dims each) and walks 64 / LPK keys per load instruction, DEC_U instructions in flight.  Scores go to LDS, the
-// softmax runs over them in fp32, then the same walk over V with the probabilities.  Same masking rule as the tiled
-// kernels: masked scores become -FLT_MAX (a fully masked row averages all keys).
-constexpr int DEC_U = 32;     // 16 x 1 KiB per wave in flight: the walk is latency bound below that (4 waves per CU)
+// One new query per sample against a cache of Sk keys: the work is reading K and V once, and at decode batch sizes the
+// kernel is a chain of dependent HBM round trips (measured 19.7 us at B = 8 and 23.3 us at B = 32 with one wave walking
+// all keys of a head: latency, not bytes).  So the walk is cut short instead: a workgroup = 4 neighbouring heads of one
+// sample (their K / V slices are adjacent in the [S, E] cache rows) x DEC_WPH waves per head, each wave taking every
+// DEC_WPH-th group of keys; a wave gives LPK lanes to a key (16 bytes = 8 head dims each) and walks 64 / LPK keys per load
+// instruction, DEC_U instructions in flight - 160 keys are ONE batch of loads per wave for K and one for V.  Scores go
+// to LDS; every wave of a head reduces max / sum over all of them itself (no second exchange); the partial outputs of the
+// DEC_WPH waves are summed through LDS in wave order.  Same masking rule as the tiled kernels: masked scores become
+// -FLT_MAX (a fully masked row averages all keys).
+constexpr int DEC_U = 10;
 
-template <int LPK>
-__global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
+// DEC_WPH: 4 when the grid fits the chip once (one 16-wave workgroup per CU), fewer for larger batches, where several
+// smaller workgroups per CU overlap their latency chains instead
+template <int LPK, int DEC_WPH>
+__global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                           int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv, bf16_t* __restrict__ out,
                                                           int64_t ldo, int64_t bsq, int64_t bsk, const int32_t* __restrict__ key_mask,
                                                           int64_t ld_mask, float* __restrict__ lse, int H, int Sk, int hd, float scale) {
-    extern __shared__ float dec_sc[];                 // [4 heads][Sk]
+    extern __shared__ float dec_sc[];                 // [4 heads][Sk] scores, then [4][DEC_WPH][128] partial outputs
     constexpr int KPI = 64 / LPK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.x, h = blockIdx.y * 4 + wave;
-    if (h >= H) return;
+    const int hh = wave / DEC_WPH, part = wave % DEC_WPH;
+    const int b = blockIdx.x, h = blockIdx.y * 4 + hh;
+    const bool head_ok = h < H;
     const int sub = lane / LPK, dl = lane % LPK;
-    const bool active = 8 * dl < hd;
-    float* sc = dec_sc + wave * Sk;
+    const bool active = head_ok && 8 * dl < hd;
+    float* sc = dec_sc + hh * Sk;
+    float* opart = dec_sc + 4 * Sk + (hh * DEC_WPH + part) * 128;
     float qf[8];
     {
         bf16x8 t = {};
@@ -448,59 +455,58 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     const bf16_t* kb = k + (int64_t)b * bsk * ldk + h * hd + 8 * dl;
     const bf16_t* vb = v + (int64_t)b * bsk * ldv + h * hd + 8 * dl;
     const int32_t* mrow = key_mask ? key_mask + (int64_t)b * ld_mask : nullptr;
+    // key of (batch start j0, slot u): groups of KPI keys are dealt round-robin to the DEC_WPH waves of the head
+    auto key_of = [&](int j0, int u) { return j0 + (u * DEC_WPH + part) * KPI + sub; };
+    constexpr int STEP = KPI * DEC_WPH * DEC_U;
 
-    for (int j0 = 0; j0 < Sk; j0 += KPI * DEC_U) {
+    for (int j0 = 0; j0 < Sk; j0 += STEP) {
         bf16x8 kv[DEC_U];
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
-            const int j = j0 + u * KPI + sub;
+            const int j = key_of(j0, u);
             kv[u] = (bf16x8){};
             if (active && j < Sk) kv[u] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)j * ldk);
         }
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
-            const int j = j0 + u * KPI + sub;
+            const int j = key_of(j0, u);
             float d = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) d += qf[e] * (float)kv[u][e];
 #pragma unroll
             for (int o = LPK >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-            if (dl == 0 && j < Sk) sc[j] = (mrow && mrow[j] == 0) ? -FLT_MAX : d * scale;
+            if (head_ok && dl == 0 && j < Sk) sc[j] = (mrow && mrow[j] == 0) ? -FLT_MAX : d * scale;
         }
     }
-    // the first batch of V does not depend on the scores: fetch it under the softmax
+    // the first batch of V does not depend on the scores: fetch it under the exchange and the softmax
     bf16x8 v0[DEC_U];
 #pragma unroll
     for (int u = 0; u < DEC_U; ++u) {
-        const int j = u * KPI + sub;
+        const int j = key_of(0, u);
         v0[u] = (bf16x8){};
         if (active && j < Sk) v0[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
     }
+    __syncthreads();
     float mx = -FLT_MAX;
     for (int j = lane; j < Sk; j += 64) mx = fmaxf(mx, sc[j]);
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int j = lane; j < Sk; j += 64) {
-        const float pj = __expf(sc[j] - mx);
-        sc[j] = pj;
-        sum += pj;
-    }
+    for (int j = lane; j < Sk; j += 64) sum += __expf(sc[j] - mx);
     sum = wave_sum(sum);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
 
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < Sk; j0 += KPI * DEC_U) {
+    for (int j0 = 0; j0 < Sk; j0 += STEP) {
         bf16x8 vv[DEC_U];
         float pj[DEC_U];
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
-            const int j = j0 + u * KPI + sub;
+            const int j = key_of(j0, u);
             if (j0 == 0) vv[u] = v0[u];
             else {
                 vv[u] = (bf16x8){};
                 if (active && j < Sk) vv[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
             }
-            pj[u] = (active && j < Sk) ? sc[j] : 0.f;
+            pj[u] = (active && j < Sk) ? __expf(sc[j] - mx) : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u)
@@ -511,14 +517,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(const bf16_t* __restri
     for (int e = 0; e < 8; ++e)
 #pragma unroll
         for (int off = LPK; off < 64; off <<= 1) o[e] += __shfl_xor(o[e], off, 64);
+    __syncthreads();                                  // every wave is done reading the scores: reuse nothing of theirs
     if (sub == 0 && active) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) opart[8 * dl + e] = o[e];
+    }
+    __syncthreads();
+    if (part == 0 && sub == 0 && active) {
+        const float* p0 = dec_sc + 4 * Sk + hh * DEC_WPH * 128 + 8 * dl;
         const float inv = 1.f / sum;
         bf16x8 r;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (bf16_t)(o[e] * inv);
+        for (int e = 0; e < 8; ++e) {
+            float t = p0[e];
+#pragma unroll
+            for (int w = 1; w < DEC_WPH; ++w) t += p0[w * 128 + e];
+            r[e] = (bf16_t)(t * inv);
+        }
         *reinterpret_cast<bf16x8*>(out + (int64_t)b * bsq * ldo + h * hd + 8 * dl) = r;
     }
-    if (lse && lane == 0) lse[(int64_t)b * H + h] = mx + __logf(sum);
+    if (lse && head_ok && part == 0 && lane == 0) lse[(int64_t)b * H + h] = mx + __logf(sum);
 }
 
 bool decode_supported(int dtype, int Sq, int Sk, int hd, const int32_t* cu, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo) {
@@ -553,13 +571,18 @@ extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int 
     if (decode_supported(dtype, Sq, Sk, hd, cu_seqlens, ldq, ldk, ldv, ldo) && !g_force_valu && eavqa_aligned16(q) && eavqa_aligned16(k) &&
         eavqa_aligned16(v) && eavqa_aligned16(o)) {
         const dim3 grid(B, (H + 3) / 4);
-        const size_t lds = (size_t)4 * Sk * sizeof(float);
+        const int blocks = B * ((H + 3) / 4);
+        const int wph = blocks <= 256 ? 4 : (blocks <= 512 ? 2 : 1);
+        const size_t lds = ((size_t)4 * Sk + 4 * wph * 128) * sizeof(float);
 #define EAVQA_DEC(LPK)                                                                                                       \
-    hipLaunchKernelGGL(attn_decode_kernel<LPK>, grid, dim3(256), lds, s, reinterpret_cast<const bf16_t*>(q), ldq,              \
+    if (wph == 4) EAVQA_DEC2(LPK, 4); else if (wph == 2) EAVQA_DEC2(LPK, 2); else EAVQA_DEC2(LPK, 1)
+#define EAVQA_DEC2(LPK, WPH)                                                                                                 \
+    hipLaunchKernelGGL((attn_decode_kernel<LPK, WPH>), grid, dim3(256 * WPH), lds, s, reinterpret_cast<const bf16_t*>(q), ldq,  \
                        reinterpret_cast<const bf16_t*>(k), ldk, reinterpret_cast<const bf16_t*>(v), ldv,                      \
                        reinterpret_cast<bf16_t*>(o), ldo, p.bsq, p.bsk, key_mask, p.ld_mask, lse, H, Sk, hd, scale)
-        if (hd <= 64) EAVQA_DEC(8); else EAVQA_DEC(16);
+        if (hd <= 64) { EAVQA_DEC(8); } else { EAVQA_DEC(16); }
 #undef EAVQA_DEC
+#undef EAVQA_DEC2
         EAVQA_LAUNCH_CHECK();
         return EAVQA_OK;
     }

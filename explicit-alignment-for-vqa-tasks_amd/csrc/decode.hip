@@ -20,7 +20,7 @@ namespace {
 __device__ __forceinline__ int fswz(int row, int kc) { return row * 64 + ((kc ^ ((-(row >> 2)) & 3)) << 4); }
 
 constexpr int SK_COLS = 64;       // columns per workgroup (4 waves x 16)
-constexpr int SK_UNROLL = 32;     // weight loads in flight per wave (16 KiB): fewer dependent HBM round trips per slice
+constexpr int SK_UNROLL = 8;      // weight loads in flight per wave (16 KiB): fewer dependent HBM round trips per slice
 
 template <int MF>
 __global__ __launch_bounds__(256) void gemm_bf16_splitk_kernel(const bf16_t* __restrict__ A, int64_t lda,

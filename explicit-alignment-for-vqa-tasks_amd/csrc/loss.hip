@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int S, int V, const float* 
 
 __global__ __launch_bounds__(256) void greedy_pick_kernel(int V, const float* logits, int64_t ld, int64_t pad, int64_t eos,
                                                           int32_t* raw, int64_t* emitted, int64_t ld_emitted,
-                                                          int32_t* unfinished) {
+                                                          int32_t* unfinished, float* logprob) {
     __shared__ float sv[256];
     __shared__ int si[256];
     const int b = blockIdx.x;
@@ -131,6 +131,19 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(int V, const float* lo
             unfinished[b] = u * (e != eos ? 1 : 0);   // :458-461
         }
         emitted[(int64_t)b * ld_emitted] = e;
+    }
+    if (logprob) {     // log_softmax(logits[b])[argmax] = -log(sum exp(x - max)); fixed-order tree
+        const float mx = sv[0];
+        __syncthreads();
+        float sum = 0.f;
+        for (int c = threadIdx.x; c < V; c += 256) sum += expf(x[c] - mx);
+        sv[threadIdx.x] = sum;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) sv[threadIdx.x] += sv[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) logprob[b] = -logf(sv[0]);
     }
 }
 
@@ -166,12 +179,13 @@ extern "C" int eavqa_ce_bwd(int dtype, int B, int S, int V, const float* logits,
 }
 
 extern "C" int eavqa_greedy_pick(int B, int V, const float* logits, int64_t ld, int64_t pad_token_id, int64_t eos_token_id,
-                                 int32_t* raw, int64_t* emitted, int64_t ld_emitted, int32_t* unfinished, void* stream) {
+                                 int32_t* raw, int64_t* emitted, int64_t ld_emitted, int32_t* unfinished, float* logprob,
+                                 void* stream) {
     if (B <= 0 || V <= 0 || !logits || !raw || !emitted) return EAVQA_E_ARG;
     if (eos_token_id >= 0 && !unfinished) return EAVQA_E_ARG;
     if (ld < V) return EAVQA_E_ARG;
     hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), V, logits, ld,
-                       pad_token_id, eos_token_id, raw, emitted, ld_emitted, unfinished);
+                       pad_token_id, eos_token_id, raw, emitted, ld_emitted, unfinished, logprob);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }

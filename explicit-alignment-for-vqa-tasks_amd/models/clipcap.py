@@ -464,7 +464,7 @@ class ClipCaptionModel(nn.Module):
 
     def _generate_from_rows(self, rows, tok, qm, stride, off, max_length: Optional[int] = 10,
                             pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None,
-                            use_cache: bool = True) -> List[List[int]]:
+                            use_cache: bool = True, output_scores: bool = False):
         """``_generate_from_embeddings`` clipcap.py:387-471 (greedy; finished rows emit pad; the embedding
         fed back is the RAW argmax :423; early stop :463)."""
         from .decode import greedy_decode
@@ -479,14 +479,14 @@ class ClipCaptionModel(nn.Module):
         tok_ext = torch.cat([tok, torch.zeros((B, max_length), dtype=tok.dtype, device=tok.device)], dim=1)
         qm_ext = torch.cat([qm.to(torch.int64), torch.ones((B, max_length), dtype=torch.int64, device=tok.device)], dim=1)
         src, mask, pos = ops.build_prefix_rows(tok_ext, qm_ext, L, lm.cfg.pos_mode, stride, off)
-        return greedy_decode(lm, rows, src, mask, pos, B, L + T, max_length, pad_token_id, eos_token_id, use_cache)
+        return greedy_decode(lm, rows, src, mask, pos, B, L + T, max_length, pad_token_id, eos_token_id, use_cache, output_scores)
 
 
     @torch.no_grad()
     def generate_fewshot(self, question_tokens: Tensor, prefix: Tensor, question_mask: Optional[Tensor] = None,
                          num_shots: Optional[int] = None, special_token_id: int = 32099, max_length: Optional[int] = 10,
                          pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None,
-                         use_cache: bool = True) -> List[List[int]]:
+                         use_cache: bool = True, output_scores: bool = False):
         """Few-shot prompt path: the causal-LM counterpart of ``VCT0Model.generate`` with
         ``insert_prefix_into_input`` (src/models/vct0.py:446-464,494-533).  ``prefix``: [B, n_img, D] (or
         [B, n_img, 1, D]) CLIP embeddings; the n-th sentinel token (ids ``special_token_id - i``) of each row
@@ -515,7 +515,7 @@ class ClipCaptionModel(nn.Module):
         if not bool((status == n_img).all().item()):
             raise ValueError("every row must hold exactly one sentinel token per image")   # vct0.py:512 .view fails
         S0 = T + (L - 1) * n_img
-        return greedy_decode(lm, rows, src, mask, pos, B, S0, max_length, pad_token_id, eos_token_id, use_cache)
+        return greedy_decode(lm, rows, src, mask, pos, B, S0, max_length, pad_token_id, eos_token_id, use_cache, output_scores)
 
 
 class ClipCaptionPrefix(ClipCaptionModel):

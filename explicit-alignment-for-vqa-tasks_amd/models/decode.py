@@ -22,14 +22,18 @@ Tensor = torch.Tensor
 
 
 def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Tensor, pos: Tensor, B: int, S0: int,
-                  max_length: int, pad_token_id: Optional[int], eos_token_id: Optional[int], use_cache: bool = True) -> List[List[int]]:
+                  max_length: int, pad_token_id: Optional[int], eos_token_id: Optional[int], use_cache: bool = True,
+                  output_scores: bool = False):
     """``src/mask/pos``: int32 [B, S0 + max_length] for the whole horizon (appended positions have mask 1;
-    their ``src`` entries are filled in as tokens are produced)."""
+    their ``src`` entries are filled in as tokens are produced).  ``output_scores``: also return the float32
+    [B, produced] log-probabilities of the raw greedy tokens (what HF's ``output_scores=True`` yields after
+    ``log(softmax)``, few_shot_vqa_executor.py:301-314)."""
     dev = lm.device
     S_max = S0 + max_length
     tokens = torch.zeros((B, max_length), dtype=torch.int64, device=dev)
     raw = torch.empty(B, dtype=torch.int32, device=dev)
     unfinished = torch.ones(B, dtype=torch.int32, device=dev)
+    logp = torch.zeros((max_length, B), dtype=torch.float32, device=dev) if output_scores else None
     produced = 0
     if use_cache:
         cache = _KVCache(lm, B, S_max, B * S0)
@@ -39,14 +43,18 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
             S = S0 + t
             logits = lm.forward(prefix_rows, src[:, :S].contiguous(), pos[:, :S].contiguous(), mask[:, :S].contiguous(),
                                 B, S, logits="last")["logits"]
-        ops.greedy_pick(logits, lm.vocab, pad_token_id, eos_token_id, raw, tokens[:, t], unfinished)
+        ops.greedy_pick(logits, lm.vocab, pad_token_id, eos_token_id, raw, tokens[:, t], unfinished,
+                        logp[t] if output_scores else None)
         produced = t + 1
         src[:, S0 + t] = raw                                   # the RAW argmax is what gets embedded (clipcap.py:423)
         if eos_token_id is not None and int(unfinished.max().item()) == 0:
             break                                              # clipcap.py:463
         if t + 1 < max_length and use_cache:
             logits = _decode_step(lm, cache, raw, pos[:, S0 + t].contiguous(), mask, B, S0 + t, S_max)
-    return tokens[:, :produced].cpu().numpy().astype(int).tolist()   # clipcap.py:469
+    ids = tokens[:, :produced].cpu().numpy().astype(int).tolist()   # clipcap.py:469
+    if output_scores:
+        return ids, logp[:produced].t().contiguous().cpu()
+    return ids
 
 
 class _KVCache:

@@ -233,12 +233,12 @@ def ce_bwd(logits: Tensor, labels: Tensor, V: int, row_lse: Tensor, count: Tenso
 
 
 def greedy_pick(logits: Tensor, V: int, pad_token_id: int, eos_token_id: Optional[int], raw: Tensor, emitted_col: Tensor,
-                unfinished: Tensor) -> None:
-    """``emitted_col``: int64 view [B] of column t of the [B, max_length] token matrix."""
+                unfinished: Tensor, logprob: Optional[Tensor] = None) -> None:
+    """``emitted_col``: int64 view [B] of column t of the [B, max_length] token matrix; ``logprob``: float32 [B] or None."""
     B = logits.shape[0]
     call("eavqa_greedy_pick", B, V, _p(logits), _ld(logits), int(pad_token_id if pad_token_id is not None else 0),
          int(eos_token_id) if eos_token_id is not None else -1, _p(raw), _p(emitted_col), emitted_col.stride(0),
-         _p(unfinished), _stream())
+         _p(unfinished), _p(logprob), _stream())
 
 
 def adamw(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999,

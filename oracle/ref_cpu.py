@@ -267,19 +267,23 @@ def clipcap_forward(sd, cfg, mapper, mcfg, question_tokens: Tensor, prefix: Tens
 
 def clipcap_generate(sd, cfg, mapper, mcfg, question_tokens: Tensor, prefix: Tensor, question_mask: Tensor,
                      max_length: int = 10, pad_token_id: Optional[int] = None,
-                     eos_token_id: Optional[int] = None) -> List[List[int]]:
+                     eos_token_id: Optional[int] = None, output_scores: bool = False):
     """``generate`` + ``_generate_from_embeddings`` clipcap.py:344-471: greedy decode by full
     re-forward each step (no KV cache); the embedding appended is that of the RAW argmax
     (:423) while the emitted token is pad-substituted for finished rows (:431-434, float
-    math on ``unfinished_sequences`` :408-410); early stop when all rows finished (:463)."""
+    math on ``unfinished_sequences`` :408-410); early stop when all rows finished (:463).
+    ``output_scores``: also the [B, steps] log-softmax of the raw argmax (``torch.log(torch.stack(
+    outputs.scores).softmax(-1))`` gathered at the token, few_shot_vqa_executor.py:314-321)."""
     emb, am = _prefix_inputs(sd, cfg, mapper, mcfg, question_tokens, prefix, question_mask)
     wte = _wte(sd, cfg)
     B = emb.shape[0]
     unfinished = torch.ones(B, 1)
     tokens = None
+    scores = []
     for _ in range(max_length):
         logits = lm_logits(sd, cfg, emb, am)
         nxt = torch.argmax(logits[:, -1, :], -1).unsqueeze(1)
+        scores.append(torch.log_softmax(logits[:, -1, :].float(), -1).gather(1, nxt))
         nxt_embed = wte[nxt]
         if eos_token_id is not None:
             if pad_token_id is None:
@@ -292,7 +296,10 @@ def clipcap_generate(sd, cfg, mapper, mcfg, question_tokens: Tensor, prefix: Ten
             unfinished = unfinished.mul((nxt != eos_token_id).long())
         if unfinished.max() == 0:
             break
-    return tokens.cpu().numpy().astype(int).tolist()
+    ids = tokens.cpu().numpy().astype(int).tolist()
+    if output_scores:
+        return ids, torch.cat(scores, dim=1)
+    return ids
 
 
 # --------------------------------------------------------------------------

@@ -108,6 +108,27 @@ def test_generate_ids_exact_fp32(mapping_type, use_cache):
 
 
 @pytest.mark.parametrize("use_cache", [True, False])
+def test_generate_scores_match_oracle_fp32(use_cache):
+    """``output_scores=True``: per-token log-probabilities (what the few-shot ensembling sums,
+    few_shot_vqa_executor.py:314-322) against the oracle's log_softmax at the greedy token."""
+    from oracle import ref_cpu
+    z = load_golden("clipcap_gpt2_mlp.npz")
+    model = build_model(z, "gpt2", "mlp", torch.float32).eval()
+    kw = dict(question_tokens=T(z["gen_ids"]), prefix=T(z["prefix"]), question_mask=T(z["gen_mask"]), max_length=6,
+              pad_token_id=int(z["pad_id"]), eos_token_id=None)
+    ids, lp = model.generate(use_cache=use_cache, output_scores=True, **kw)
+    assert ids == z["gen_free"].tolist() and tuple(lp.shape) == (len(ids), len(ids[0]))
+    V, E, NLAY, NH, NPOS, L, D, CL, NL = [int(v) for v in z["cfg"]]
+    with torch.no_grad():
+        oids, olp = ref_cpu.clipcap_generate(sub(z, "lm."), dict(arch="gpt2", n_layer=NLAY, n_head=NH), sub(z, "map."),
+                                             dict(prefix_length=L, clip_length=CL, num_layers=NL, mapping_type="mlp"), T(z["gen_ids"]),
+                                             T(z["prefix"]), T(z["gen_mask"]), max_length=6, pad_token_id=int(z["pad_id"]),
+                                             eos_token_id=None, output_scores=True)
+    assert oids == ids
+    assert (lp - olp).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("use_cache", [True, False])
 def test_generate_opt_ids_exact_fp32(use_cache):
     z = load_golden("clipcap_opt_mlp.npz")
     model = build_model(z, "opt", "mlp", torch.float32).eval()

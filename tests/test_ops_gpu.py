@@ -445,6 +445,10 @@ def test_greedy_pick_first_max_and_finished_rows(ops):
     assert toks[:, 2].cpu().tolist() == [17, 999, 42, 0]     # finished row emits pad (clipcap.py:431-434)
     assert unf.cpu().tolist() == [1, 0, 0, 1]                # row 1 just produced eos (clipcap.py:458-461)
     ops.greedy_pick(logits.to(DEV), V, 42, None, raw, toks[:, 3], unf)   # eos None: raw tokens, flags untouched
+    lp = torch.empty(logits.shape[0], device=DEV)
+    ops.greedy_pick(logits.to(DEV), V, 42, None, raw, toks[:, 3], unf, lp)
+    want = torch.log_softmax(logits.double(), -1).max(-1).values.float()
+    assert (lp.cpu() - want).abs().max().item() <= 1e-5
     assert toks[:, 3].cpu().tolist() == [17, 999, 5, 0] and unf.cpu().tolist() == [1, 0, 0, 1]
 
 
