@@ -129,3 +129,39 @@ def test_generative_step_contract(dtype):
     assert [p["question_id"] for p in out["predictions"]] == [11, 12, 13, 14]
     assert len(out["outputs"]) == 4 and all(1 <= len(o) <= 4 for o in out["outputs"])
     assert all(isinstance(p["answer"], str) for p in out["predictions"])
+
+
+def test_fit_from_a_conceptual_captions_parquet_store(tmp_path):
+    """Batches read from the reference's parquet store format (data/stores.py) drive the executor's CC branch
+    (labels come masked from the collate, data_loader_conceptual_captions.py:94-95); first loss equals the oracle's."""
+    import types
+    from eavqa_amd.data import stores
+    z = load_golden("clipcap_gpt2_mlp.npz")
+    ex, tok, (V, E, NLAY, NH, L, D) = make_executor(z, torch.float32)
+    ex.config.data_loader.type = "DataLoaderConceptualCaptions"
+    g = torch.Generator().manual_seed(5)
+    N = 12
+    emb = torch.randn(N, D, generator=g)
+    ids = [torch.randint(0, V - 3, (int(n),), generator=g).tolist() for n in torch.randint(3, 9, (N,), generator=g)]
+    caps = [" ".join(str(t) for t in row) + " ." for row in ids]
+    path = str(tmp_path / "cc.parquet")
+    stores.write_cc_parquet(path, [f"u{i}" for i in range(N)], caps, emb, wrap=True, row_group_size=5)
+
+    class IdTokenizer:     # captions are already "token id" strings; the trailing period maps to eos like a sentence end
+        pad_token_id = tok.eos_token_id
+
+        def __call__(self, texts, padding, max_length, truncation, return_tensors):
+            rows = [[tok.eos_token_id if w == "." else int(w) for w in t.split()][:max_length] for t in texts]
+            T_ = max(len(r) for r in rows)
+            return types.SimpleNamespace(input_ids=torch.tensor([r + [self.pad_token_id] * (T_ - len(r)) for r in rows]),
+                                         attention_mask=torch.tensor([[1] * len(r) + [0] * (T_ - len(r)) for r in rows]))
+
+    batches = list(stores.ConceptualCaptionsParquet(path).iter_batches(4, IdTokenizer(), max_source_length=8))
+    assert len(batches) == 3 and tuple(batches[0]["clip_embeddings"].shape) == (4, D)
+    losses = ex.fit(batches, accumulate_grad_batches=1)
+    assert ex.global_step == 3 and all(torch.isfinite(l) for l in losses)
+    b = batches[0]
+    mapper = sub(z, "map.")
+    want, _ = oracle.clipcap_forward(sub(z, "lm."), dict(arch="gpt2", n_layer=NLAY, n_head=NH), mapper, dict(prefix_length=L, mapping_type="mlp"),
+                                     b["input_ids"], b["clip_embeddings"], b["attention_mask"], b["labels"])
+    assert abs(losses[0].item() - want.item()) <= 2e-4
