@@ -321,3 +321,22 @@ def layernorm_splitk(x_in: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_
     call("eavqa_layernorm_splitk", dtype_id(out_dtype), rows, cols, _p(x_in), _ld(x_in), _p(part), 0 if part is None else part.shape[0],
          _p(bias), _p(x_out), _ld(x_out) if x_out is not None else 0, _p(gamma), _p(beta), float(eps), _p(y), _ld(y), _stream())
     return y
+
+
+def l2_normalize_rows_(x: Tensor) -> Tensor:
+    """In place, fp32 [rows, cols] (faiss.normalize_L2)."""
+    if x.dtype != torch.float32:
+        raise _lib.EavqaError("l2_normalize_rows_: float32 only")
+    call("eavqa_l2_normalize_rows", x.shape[0], x.shape[1], _p(x), _ld(x), _stream())
+    return x
+
+
+def topk_rows(scores: Tensor, k: int):
+    """(values float32 [rows, k] descending, indices int64 [rows, k]); ties go to the smaller column."""
+    if scores.dtype != torch.float32:
+        raise _lib.EavqaError("topk_rows: float32 scores only")
+    rows, cols = scores.shape
+    val = torch.empty((rows, k), device=scores.device, dtype=torch.float32)
+    idx = torch.empty((rows, k), device=scores.device, dtype=torch.int64)
+    call("eavqa_topk_rows", rows, cols, _p(scores), _ld(scores), int(k), _p(val), _p(idx), _stream())
+    return val, idx

@@ -281,6 +281,14 @@ int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int
                            const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
                            float eps, void* y, int64_t ldy, void* stream);
 
+/* ---- RICES retrieval (src/in_context_example_selection/get_question_knn.py:64-76: faiss.normalize_L2 +
+ * IndexFlatIP.search with k = 2048).  The scores are eavqa_gemm in fp32 (queries [Nq, D] x database [Nd, D]^T).
+ * eavqa_l2_normalize_rows: x[r, :] /= ||x[r, :]||_2 in place (rows of norm 0 untouched, as faiss).
+ * eavqa_topk_rows: per row the k largest scores sorted descending (ties: smaller column first), k <= 2048, k <= cols;
+ * out_val float32 [rows, k], out_idx int64 [rows, k] (faiss's D and I). */
+int eavqa_l2_normalize_rows(int rows, int cols, float* x, int64_t ld, void* stream);
+int eavqa_topk_rows(int rows, int cols, const float* scores, int64_t ld, int k, float* out_val, int64_t* out_idx, void* stream);
+
 /* float32 -> `dtype` elementwise copy with row strides (casts the residual stream / pooled rows). */
 int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream);
 
