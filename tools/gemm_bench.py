@@ -24,6 +24,8 @@ SHAPES = [  # (M, N, K, what)
     (2688, 1280, 50304, "lm_head dgrad"), (3200, 2304, 768, "vit qkv"), (3200, 768, 768, "vit proj"),
     (1024, 1280, 5120, "probe 80 tiles"), (2048, 1280, 5120, "probe 160 tiles"), (2048, 2048, 5120, "probe 256 tiles"),
     (2048, 3072, 5120, "probe 384 tiles"), (2048, 4096, 5120, "probe 512 tiles"), (4096, 4096, 5120, "probe 1024 tiles"),
+    (41120, 3072, 1024, "vitL qkv"), (41120, 1024, 1024, "vitL proj"), (41120, 4096, 1024, "vitL fc1"), (41120, 1024, 4096, "vitL fc2"),
+    (4800, 7680, 2560, "prefill qkv"), (4800, 2560, 2560, "prefill proj"), (4800, 10240, 2560, "prefill fc1"), (4800, 2560, 10240, "prefill fc2"),
     (3200, 3072, 768, "vit fc1"), (3200, 768, 3072, "vit fc2"), (4096, 4096, 4096, "square 4k"), (8192, 8192, 8192, "square 8k"),
 ]
 
