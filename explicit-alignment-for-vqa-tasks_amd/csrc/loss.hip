@@ -98,22 +98,25 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int S, int V, const float* 
     }
 }
 
-__global__ __launch_bounds__(256) void greedy_pick_kernel(int V, const float* logits, int64_t ld, int64_t pad, int64_t eos,
+// one 1024-thread workgroup per row: a decode step has at most 64 rows, the parallelism has to come from inside the row
+constexpr int GP_THREADS = 1024;
+
+__global__ __launch_bounds__(GP_THREADS) void greedy_pick_kernel(int V, const float* logits, int64_t ld, int64_t pad, int64_t eos,
                                                           int32_t* raw, int64_t* emitted, int64_t ld_emitted,
                                                           int32_t* unfinished, float* logprob) {
-    __shared__ float sv[256];
-    __shared__ int si[256];
+    __shared__ float sv[GP_THREADS];
+    __shared__ int si[GP_THREADS];
     const int b = blockIdx.x;
     const float* x = logits + (int64_t)b * ld;
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int c = threadIdx.x; c < V; c += 256) {
+    for (int c = threadIdx.x; c < V; c += GP_THREADS) {
         const float v = x[c];
         if (v > best || idx == 0x7fffffff) { best = v; idx = c; }   // strict >: first maximal index wins
     }
     sv[threadIdx.x] = best; si[threadIdx.x] = idx;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = GP_THREADS / 2; o > 0; o >>= 1) {
         if (threadIdx.x < o) {
             const float v2 = sv[threadIdx.x + o];
             const int i2 = si[threadIdx.x + o];
@@ -136,10 +139,10 @@ __global__ __launch_bounds__(256) void greedy_pick_kernel(int V, const float* lo
         const float mx = sv[0];
         __syncthreads();
         float sum = 0.f;
-        for (int c = threadIdx.x; c < V; c += 256) sum += expf(x[c] - mx);
+        for (int c = threadIdx.x; c < V; c += GP_THREADS) sum += expf(x[c] - mx);
         sv[threadIdx.x] = sum;
         __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
+        for (int o = GP_THREADS / 2; o > 0; o >>= 1) {
             if (threadIdx.x < o) sv[threadIdx.x] += sv[threadIdx.x + o];
             __syncthreads();
         }
@@ -184,7 +187,7 @@ extern "C" int eavqa_greedy_pick(int B, int V, const float* logits, int64_t ld, 
     if (B <= 0 || V <= 0 || !logits || !raw || !emitted) return EAVQA_E_ARG;
     if (eos_token_id >= 0 && !unfinished) return EAVQA_E_ARG;
     if (ld < V) return EAVQA_E_ARG;
-    hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), V, logits, ld,
+    hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(GP_THREADS), 0, reinterpret_cast<hipStream_t>(stream), V, logits, ld,
                        pad_token_id, eos_token_id, raw, emitted, ld_emitted, unfinished, logprob);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;

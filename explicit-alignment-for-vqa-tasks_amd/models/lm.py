@@ -328,7 +328,11 @@ class FrozenCausalLM:
     def _head(self, hf: Tensor) -> Tensor:
         """lm_head GEMM into a [rows, vpad] fp32 buffer (pad columns are never read)."""
         lg = torch.empty((hf.shape[0], self.vpad), device=self.device, dtype=torch.float32)
-        ops.gemm(hf, self.head, out=lg[:, :self.vocab])
+        if hf.shape[0] <= 64 and hf.dtype == torch.bfloat16 and self.vocab % 4 == 0 and self.cfg.n_embd % 32 == 0:
+            # a decode step: stream the [V, E] head once with K split over workgroups (csrc/decode.hip)
+            ops.splitk_finish(ops.gemm_splitk(hf, self.head[:self.vocab]), [lg[:, :self.vocab]])
+        else:
+            ops.gemm(hf, self.head, out=lg[:, :self.vocab])
         return lg
 
     # ---------------------------------------------------------------- backward (dgrad only)
