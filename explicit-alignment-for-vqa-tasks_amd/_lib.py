@@ -83,6 +83,10 @@ def load() -> C.CDLL:
             f"{LIB_PATH} is missing: the HIP extension is the only compute path. "
             "Build it with `python -m eavqa_amd.build` (needs hipcc, no GPU required to compile)."
         )
+    # torch ships its own libamdhip64: it must be in the process before this library asks the loader for that SONAME,
+    # otherwise the system runtime gets bound first and torch later runs on a HIP runtime it was not built against
+    # (seen as hipGetDevice failing when build() and smoke() share one process)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch: fail loudly

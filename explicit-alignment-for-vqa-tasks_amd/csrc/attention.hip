@@ -16,6 +16,7 @@
 namespace {
 
 bool g_force_valu = false;   // test hook: keep bf16 on the vector-ALU kernels
+bool g_split_bwd = false;    // test hook: two-kernel backward even when the problem is one tile
 
 constexpr int CK = 8;  // keys per softmax chunk
 
@@ -597,7 +598,7 @@ extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int 
     return dtype == EAVQA_F32 ? dispatch<float>(K_FWD, p, s) : dispatch<bf16_t>(K_FWD, p, s);
 }
 
-extern "C" void eavqa_debug_attention_valu(int force) { g_force_valu = force != 0; }
+extern "C" void eavqa_debug_attention_valu(int force) { g_force_valu = (force & 1) != 0; g_split_bwd = (force & 2) != 0; }
 
 extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int hd,
                                    const void* q, int64_t ldq, const void* k, int64_t ldk,
@@ -625,6 +626,7 @@ extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int 
         m.key_mask = key_mask; m.ld_mask = Sk; m.cu = cu_seqlens; m.lse = const_cast<float*>(lse); m.delta = delta;
         m.B = B; m.H = H; m.Sq = Sq; m.Sk = Sk; m.hd = hd; m.causal = causal; m.stat_ld = Sq;
         m.bsq = Sq; m.bsk = Sk; m.scale = scale;
+        if (Sq <= eavqa_attn_mfma::TILE && Sk <= eavqa_attn_mfma::TILE && !g_split_bwd) return eavqa_attn_mfma::run(3, m, s);
         rc = eavqa_attn_mfma::run(1, m, s);
         if (rc) return rc;
         return eavqa_attn_mfma::run(2, m, s);

@@ -358,6 +358,120 @@ __global__ __launch_bounds__(256) void bwd_dkv_kernel(Params p) {
     }
 }
 
+// ------------------------------------------------------------------------------------ backward, one tile: dQ, dK, dV
+// Sq, Sk <= 64 (every training sequence of the hot path: prefix + caption <= 42 positions): the whole (batch, head)
+// problem is one tile, so one workgroup produces all three gradients and S / P / dS are computed once instead of twice.
+// Orientation of bwd_dkv_kernel (lane item = key) for P, dS, dV, dK; dS is then handed over through LDS as a row-major
+// [query][key] bf16 image and dQ^T += K^T . dS^T runs with lane item = query (A = K^T from the transposed image in
+// natural k order, B = 8 consecutive keys of the lane's query row).
+template <int KS, int D16>
+__global__ __launch_bounds__(256) void bwd_fused_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* DOs = Qs + Geo<KS>::ROW_BYTES;
+    char* Qt = DOs + Geo<KS>::ROW_BYTES;
+    char* DOt = Qt + Geo<KS>::TR_BYTES;
+    char* Kt = DOt + Geo<KS>::TR_BYTES;
+    char* DSs = Kt + Geo<KS>::TR_BYTES;                                   // [64 queries][64 keys] bf16, pitch DS_PITCH
+    constexpr int DS_PITCH = TILE * 2 + 16;
+    float* stats = reinterpret_cast<float*>(DSs + TILE * DS_PITCH);       // lse[64], delta[64]
+
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    if (!window(p, b, 0, false)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const int item = wave * 16 + x;                   // this lane's key (first half) and query (second half)
+    const int off = p.Sk - p.Sq, head_off = h * p.hd;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + p.bsq * p.ldq;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + p.bsk * p.ldk;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + p.bsk * p.ldv;
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(p.o) + p.bsq * p.ldo;
+    const bf16_t* DO = reinterpret_cast<const bf16_t*>(p.d_o) + p.bsq * p.lddo;
+
+    stage<KS>(Qs, Qt, Q, p.ldq, 0, p.Sq, p.hd, head_off);
+    stage<KS>(DOs, DOt, DO, p.lddo, 0, p.Sq, p.hd, head_off);
+    stage<KS>(nullptr, Kt, K, p.ldk, 0, p.Sk, p.hd, head_off);
+    {   // delta = rowsum(dO * O) and lse of query `item`
+        const bool qa = item < p.Sq;
+        bf16x8 dof[KS], of[KS];
+        load_bfrag<KS>(dof, DO, p.lddo, item, qa, p.hd, head_off, g);
+        load_bfrag<KS>(of, O, p.ldo, item, qa, p.hd, head_off, g);
+        float dsum = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum += (float)dof[s][j] * (float)of[s][j];
+        const float delta = group4_sum(dsum);
+        if (g == 0) {
+            const int64_t st = ((int64_t)b * p.H + h) * p.stat_ld + item;
+            stats[item] = qa ? p.lse[st] : 0.f;
+            stats[TILE + item] = qa ? delta : 0.f;
+            if (qa) p.delta[st] = delta;
+        }
+    }
+    const bool kactive = item < p.Sk;
+    bf16x8 kf[KS], vf[KS];
+    load_bfrag<KS>(kf, K, p.ldk, item, kactive, p.hd, head_off, g);
+    load_bfrag<KS>(vf, V, p.ldv, item, kactive, p.hd, head_off, g);
+    const bool kvalid = kactive && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + item] != 0);
+    __syncthreads();
+
+    f32x4 sc[4], dp[4];
+    tile_dot<KS>(sc, Qs, kf, x, g);
+    tile_dot<KS>(dp, DOs, vf, x, g);
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = 16 * f + 4 * g + r;
+            const bool exists = qq < p.Sq;
+            const bool vis = exists && kvalid && (!p.causal || item <= qq + off);
+            const float pj = exists ? __expf((vis ? sc[f][r] * p.scale : -FLT_MAX) - stats[qq]) : 0.f;
+            sc[f][r] = pj;                                                   // P
+            dp[f][r] = pj * (dp[f][r] - stats[TILE + qq]) * p.scale;        // dS
+            *reinterpret_cast<bf16_t*>(DSs + qq * DS_PITCH + item * 2) = (bf16_t)(kactive ? dp[f][r] : 0.f);
+        }
+    {
+        f32x4 dk[D16], dv[D16];
+#pragma unroll
+        for (int dm = 0; dm < D16; ++dm) { dk[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        tile_accumulate<KS, D16>(dv, DOt, sc, x, g);
+        tile_accumulate<KS, D16>(dk, Qt, dp, x, g);
+        if (kactive) {
+            bf16_t* DK = reinterpret_cast<bf16_t*>(p.dk) + p.bsk * p.lddk;
+            bf16_t* DV = reinterpret_cast<bf16_t*>(p.dv) + p.bsk * p.lddv;
+#pragma unroll
+            for (int dm = 0; dm < D16; ++dm) {
+                store4(DK, p.lddk, item, head_off, 16 * dm + 4 * g, p.hd, dk[dm], 1.f);
+                store4(DV, p.lddv, item, head_off, 16 * dm + 4 * g, p.hd, dv[dm], 1.f);
+            }
+        }
+    }
+    __syncthreads();                                  // the dS image is complete
+
+    f32x4 dq[D16];
+#pragma unroll
+    for (int dm = 0; dm < D16; ++dm) dq[dm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(DSs + item * DS_PITCH + (32 * s2 + 8 * g) * 2);
+#pragma unroll
+        for (int dm = 0; dm < D16; ++dm) {
+            const char* base = Kt + (16 * dm + x) * Geo<KS>::PT + (32 * s2 + 8 * g) * 2;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(base);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(base + 8);
+            bf16x8 a;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
+            dq[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag, dq[dm], 0, 0, 0);
+        }
+    }
+    if (item < p.Sq) {
+        bf16_t* DQ = reinterpret_cast<bf16_t*>(p.dq) + p.bsq * p.lddq;
+#pragma unroll
+        for (int dm = 0; dm < D16; ++dm) store4(DQ, p.lddq, item, head_off, 16 * dm + 4 * g, p.hd, dq[dm], 1.f);
+    }
+}
+
 template <int KS, int D16>
 int launch(int which, const Params& p, hipStream_t s) {
     const size_t row = Geo<KS>::ROW_BYTES, tr = Geo<KS>::TR_BYTES;
@@ -367,6 +481,16 @@ int launch(int which, const Params& p, hipStream_t s) {
     } else if (which == 1) {
         dim3 grid((p.Sq + TILE - 1) / TILE, p.B * p.H);
         hipLaunchKernelGGL((bwd_dq_kernel<KS, D16>), grid, dim3(256), 2 * row + tr + TILE * 4, s, p);
+    } else if (which == 3) {
+        static bool configured = false;
+        const size_t lds = 2 * row + 3 * tr + TILE * (TILE * 2 + 16) + 2 * TILE * 4;
+        if (lds > 64 * 1024 && !configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel<KS, D16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return EAVQA_E_LAUNCH;
+            configured = true;
+        }
+        hipLaunchKernelGGL((bwd_fused_kernel<KS, D16>), dim3(1, p.B * p.H), dim3(256), lds, s, p);
     } else {
         static bool configured = false;        // hd = 128: 2 x 17 KiB + 2 x 17 KiB + stats > 64 KiB
         const size_t lds = 2 * row + 2 * tr + 2 * TILE * 4;
@@ -385,7 +509,7 @@ int launch(int which, const Params& p, hipStream_t s) {
 
 bool supported(int hd) { return hd == 64 || hd == 80 || hd == 96 || hd == 128; }
 
-// which: 0 forward, 1 dQ (+delta), 2 dK/dV
+// which: 0 forward, 1 dQ (+delta), 2 dK/dV, 3 all three gradients of a one-tile problem (Sq, Sk <= 64)
 int run(int which, const Params& p, hipStream_t s) {
     switch (p.hd) {
         case 64: return launch<2, 4>(which, p, s);

@@ -187,11 +187,12 @@ def test_layernorm_bf16_input_rows_with_stride(ops):
 
 
 # --------------------------------------------------------------------------- attention
-@pytest.fixture(params=["mfma", "valu"])
+@pytest.fixture(params=["mfma", "mfma_split", "valu"])
 def attn_path(request):
-    """bf16 attention with hd in {64,80,96,128} runs on the matrix cores; run every case through both kernels."""
+    """bf16 attention with hd in {64,80,96,128} runs on the matrix cores (one-tile problems take the fused backward,
+    "mfma_split" forces the dQ + dK/dV pair); run every case through all of them and the vector-ALU kernels."""
     from eavqa_amd import _lib
-    _lib.load().eavqa_debug_attention_valu(int(request.param == "valu"))
+    _lib.load().eavqa_debug_attention_valu({"mfma": 0, "mfma_split": 2, "valu": 1}[request.param])
     yield request.param
     _lib.load().eavqa_debug_attention_valu(0)
 
