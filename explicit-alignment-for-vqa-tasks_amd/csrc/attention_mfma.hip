@@ -13,8 +13,9 @@
 //        S = Q . K^T, dP = dO . V^T, dV^T += dO^T . P, dK^T += Q^T . dS
 // An accumulator tile (rows in registers, column on the lane) is directly the B operand of the next
 // product that sums over its ROW index, so P / dS never leave registers: registers 0-3 of two adjacent
-// 16-row tiles form one 8-element B fragment; the A operand (read from a TRANSPOSED LDS image [d][item])
-// is fetched in the same permuted k order (two 8-byte reads).  Softmax statistics are per lane column:
+// 16-row tiles form one 8-element B fragment; the A operand of that product is the staged tile TRANSPOSED,
+// fetched from the row-major LDS image in the same permuted k order by two transposing reads
+// (ds_read_b64_tr_b16) - no transposed copy is written.  Softmax statistics are per lane column:
 // the reduction over register items is in-lane plus two wave shuffles (xor 16, 32).
 // Masked scores are replaced by -FLT_MAX exactly as in the vector-ALU kernels.
 #include "common.h"
@@ -38,9 +39,7 @@ constexpr int TILE = 64;
 template <int KS> struct Geo {
     static constexpr int HP = KS * 32;              // head dim padded to the MFMA k step
     static constexpr int PR = HP * 2 + 16;          // byte pitch of a row-major [item][d] image (16 B pad: bank spread)
-    static constexpr int PT = TILE * 2 + 8;         // byte pitch of a transposed [d][item] image
     static constexpr int ROW_BYTES = TILE * PR;
-    static constexpr int TR_BYTES = HP * PT;
 };
 
 __device__ __forceinline__ bf16x8 zero8() {
@@ -50,24 +49,18 @@ __device__ __forceinline__ bf16x8 zero8() {
     return z;
 }
 
-// Stage 64 rows (items row0 .. row0+63 of the current sample/head) into a row-major and/or a transposed image.
+// Stage 64 rows (items row0 .. row0+63 of the current sample/head) as a row-major [item][d] image (16-byte stores).
+// The second argument is kept for call-site symmetry and must be null: products that need the tile transposed read it
+// through ds_read_b64_tr_b16 (tile_accumulate) instead of keeping a transposed copy.
 template <int KS>
-__device__ __forceinline__ void stage(char* rowmaj, char* transposed, const bf16_t* src, int64_t ld, int row0, int n_rows,
+__device__ __forceinline__ void stage(char* rowmaj, char* /*unused*/, const bf16_t* src, int64_t ld, int row0, int n_rows,
                                       int hd, int head_off) {
     constexpr int CH = Geo<KS>::HP / 8;             // 16-byte chunks per row
     for (int c = threadIdx.x; c < TILE * CH; c += 256) {
         const int r = c / CH, ch = c - r * CH;
         uint4 val = make_uint4(0u, 0u, 0u, 0u);
         if (row0 + r < n_rows && ch * 8 < hd) val = *reinterpret_cast<const uint4*>(src + (int64_t)(row0 + r) * ld + head_off + ch * 8);
-        if (rowmaj) *reinterpret_cast<uint4*>(rowmaj + r * Geo<KS>::PR + ch * 16) = val;
-        if (transposed) {
-            const unsigned w[4] = {val.x, val.y, val.z, val.w};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const unsigned short e = (unsigned short)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu));
-                *reinterpret_cast<unsigned short*>(transposed + (ch * 8 + i) * Geo<KS>::PT + r * 2) = e;
-            }
-        }
+        *reinterpret_cast<uint4*>(rowmaj + r * Geo<KS>::PR + ch * 16) = val;
     }
 }
 
@@ -96,19 +89,32 @@ __device__ __forceinline__ void tile_dot(f32x4 (&acc)[4], const char* rowmaj, co
     }
 }
 
-// out[dm] += sum over the 64 register items of T[d = 16 dm + (lane & 15)][item] * w[item], w given as 4 accumulator tiles
+// 4 x 16 transposing LDS read (ds_read_b64_tr_b16): within a 16-lane group, lane 4q + p supplies the address of row q,
+// columns 4p .. 4p+3 of a block of 16-bit elements; lane i receives column i of the 4 rows (row q in element q).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 lds_tr4(const char* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    return __builtin_bit_cast(bf16x4, v);
+}
+
+// out[dm] += sum over the 64 register items of R[item][d = 16 dm + (lane & 15)] * w[item], w given as 4 accumulator
+// tiles.  R is the ROW-MAJOR [item][d] image: the A operand (rows = d, k = items in the permuted order of the
+// accumulator-as-B trick: items 32 s2 + 4 g .. +3 and 32 s2 + 16 + 4 g .. +3) comes out of two transposing reads, so no
+// transposed copy of the tile is ever written.
 template <int KS, int D16>
-__device__ __forceinline__ void tile_accumulate(f32x4 (&out)[D16], const char* transposed, const f32x4 (&w)[4], int x, int g) {
+__device__ __forceinline__ void tile_accumulate(f32x4 (&out)[D16], const char* rowmaj, const f32x4 (&w)[4], int x, int g) {
+    const int q = x >> 2, pp = x & 3;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         bf16x8 b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { b[r] = (bf16_t)w[2 * s2][r]; b[4 + r] = (bf16_t)w[2 * s2 + 1][r]; }
+        const char* row_lo = rowmaj + (32 * s2 + 4 * g + q) * Geo<KS>::PR + 8 * pp;
+        const char* row_hi = row_lo + 16 * Geo<KS>::PR;
 #pragma unroll
         for (int dm = 0; dm < D16; ++dm) {
-            const char* base = transposed + (16 * dm + x) * Geo<KS>::PT + (32 * s2 + 4 * g) * 2;
-            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(base);
-            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(base + 32);
+            const bf16x4 lo = lds_tr4(row_lo + 32 * dm);
+            const bf16x4 hi = lds_tr4(row_hi + 32 * dm);
             bf16x8 a;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
@@ -145,8 +151,8 @@ template <int KS, int D16>
 __global__ __launch_bounds__(256) void fwd_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
-    char* Vt = smem + Geo<KS>::ROW_BYTES;
-    int* valid = reinterpret_cast<int*>(Vt + Geo<KS>::TR_BYTES);
+    char* Vs = smem + Geo<KS>::ROW_BYTES;
+    int* valid = reinterpret_cast<int*>(Vs + Geo<KS>::ROW_BYTES);
 
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int q0 = blockIdx.x * TILE;
@@ -172,7 +178,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(Params p) {
     for (int k0 = 0; k0 < k_end; k0 += TILE) {
         __syncthreads();
         stage<KS>(Ks, nullptr, K, p.ldk, k0, p.Sk, p.hd, head_off);
-        stage<KS>(nullptr, Vt, V, p.ldv, k0, p.Sk, p.hd, head_off);
+        stage<KS>(Vs, nullptr, V, p.ldv, k0, p.Sk, p.hd, head_off);
         for (int c = threadIdx.x; c < TILE; c += 256)
             valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
         __syncthreads();
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(Params p) {
                 st[f][r] = pj;
                 lsum += pj;
             }
-        tile_accumulate<KS, D16>(acc, Vt, st, x, g);
+        tile_accumulate<KS, D16>(acc, Vs, st, x, g);
         m = m_new;
     }
     const float l = group4_sum(lsum);
@@ -221,8 +227,7 @@ __global__ __launch_bounds__(256) void bwd_dq_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = Ks + Geo<KS>::ROW_BYTES;
-    char* Kt = Vs + Geo<KS>::ROW_BYTES;
-    int* valid = reinterpret_cast<int*>(Kt + Geo<KS>::TR_BYTES);
+    int* valid = reinterpret_cast<int*>(Vs + Geo<KS>::ROW_BYTES);
 
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int q0 = blockIdx.x * TILE;
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256) void bwd_dq_kernel(Params p) {
     if (k_end < 1) k_end = min(p.Sk, 1);
     for (int k0 = 0; k0 < k_end; k0 += TILE) {
         __syncthreads();
-        stage<KS>(Ks, Kt, K, p.ldk, k0, p.Sk, p.hd, head_off);
+        stage<KS>(Ks, nullptr, K, p.ldk, k0, p.Sk, p.hd, head_off);
         stage<KS>(Vs, nullptr, V, p.ldv, k0, p.Sk, p.hd, head_off);
         for (int c = threadIdx.x; c < TILE; c += 256)
             valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
@@ -278,7 +283,7 @@ __global__ __launch_bounds__(256) void bwd_dq_kernel(Params p) {
                 const float pj = exists ? __expf((vis ? st[f][r] * p.scale : -FLT_MAX) - lse) : 0.f;
                 st[f][r] = pj * (dp[f][r] - delta) * p.scale;      // dS^T
             }
-        tile_accumulate<KS, D16>(dq, Kt, st, x, g);
+        tile_accumulate<KS, D16>(dq, Ks, st, x, g);
     }
     if (active) {
         bf16_t* DQ = reinterpret_cast<bf16_t*>(p.dq) + p.bsq * p.lddq;
@@ -293,9 +298,7 @@ __global__ __launch_bounds__(256) void bwd_dkv_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
     char* DOs = Qs + Geo<KS>::ROW_BYTES;
-    char* Qt = DOs + Geo<KS>::ROW_BYTES;
-    char* DOt = Qt + Geo<KS>::TR_BYTES;
-    float* stats = reinterpret_cast<float*>(DOt + Geo<KS>::TR_BYTES);     // lse[64], delta[64]
+    float* stats = reinterpret_cast<float*>(DOs + Geo<KS>::ROW_BYTES);    // lse[64], delta[64]
 
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int j0 = blockIdx.x * TILE;
@@ -321,8 +324,8 @@ __global__ __launch_bounds__(256) void bwd_dkv_kernel(Params p) {
     if (p.causal) q_begin = (max(0, j0 - off) / TILE) * TILE;
     for (int q0 = q_begin; q0 < p.Sq; q0 += TILE) {
         __syncthreads();
-        stage<KS>(Qs, Qt, Q, p.ldq, q0, p.Sq, p.hd, head_off);
-        stage<KS>(DOs, DOt, DO, p.lddo, q0, p.Sq, p.hd, head_off);
+        stage<KS>(Qs, nullptr, Q, p.ldq, q0, p.Sq, p.hd, head_off);
+        stage<KS>(DOs, nullptr, DO, p.lddo, q0, p.Sq, p.hd, head_off);
         for (int c = threadIdx.x; c < TILE; c += 256) {
             const bool in = q0 + c < p.Sq;
             const int64_t st = ((int64_t)b * p.H + h) * p.stat_ld + q0 + c;
@@ -344,8 +347,8 @@ __global__ __launch_bounds__(256) void bwd_dkv_kernel(Params p) {
                 sc[f][r] = pj;                                                   // P
                 dp[f][r] = pj * (dp[f][r] - stats[TILE + qq]) * p.scale;        // dS
             }
-        tile_accumulate<KS, D16>(dv, DOt, sc, x, g);
-        tile_accumulate<KS, D16>(dk, Qt, dp, x, g);
+        tile_accumulate<KS, D16>(dv, DOs, sc, x, g);
+        tile_accumulate<KS, D16>(dk, Qs, dp, x, g);
     }
     if (active) {
         bf16_t* DK = reinterpret_cast<bf16_t*>(p.dk) + p.bsk * p.lddk;
@@ -362,17 +365,16 @@ __global__ __launch_bounds__(256) void bwd_dkv_kernel(Params p) {
 // Sq, Sk <= 64 (every training sequence of the hot path: prefix + caption <= 42 positions): the whole (batch, head)
 // problem is one tile, so one workgroup produces all three gradients and S / P / dS are computed once instead of twice.
 // Orientation of bwd_dkv_kernel (lane item = key) for P, dS, dV, dK; dS is then handed over through LDS as a row-major
-// [query][key] bf16 image and dQ^T += K^T . dS^T runs with lane item = query (A = K^T from the transposed image in
-// natural k order, B = 8 consecutive keys of the lane's query row).
+// [query][key] bf16 image and dQ^T += K^T . dS^T runs with lane item = query (A = K^T in
+// natural k order, B = 8 consecutive keys of the lane's query row).  All A operands that sum over sequence items come
+// from row-major images through transposing LDS reads.
 template <int KS, int D16>
 __global__ __launch_bounds__(256) void bwd_fused_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
     char* DOs = Qs + Geo<KS>::ROW_BYTES;
-    char* Qt = DOs + Geo<KS>::ROW_BYTES;
-    char* DOt = Qt + Geo<KS>::TR_BYTES;
-    char* Kt = DOt + Geo<KS>::TR_BYTES;
-    char* DSs = Kt + Geo<KS>::TR_BYTES;                                   // [64 queries][64 keys] bf16, pitch DS_PITCH
+    char* Ks = DOs + Geo<KS>::ROW_BYTES;
+    char* DSs = Ks + Geo<KS>::ROW_BYTES;                                  // [64 queries][64 keys] bf16, pitch DS_PITCH
     constexpr int DS_PITCH = TILE * 2 + 16;
     float* stats = reinterpret_cast<float*>(DSs + TILE * DS_PITCH);       // lse[64], delta[64]
 
@@ -387,9 +389,9 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(Params p) {
     const bf16_t* O = reinterpret_cast<const bf16_t*>(p.o) + p.bsq * p.ldo;
     const bf16_t* DO = reinterpret_cast<const bf16_t*>(p.d_o) + p.bsq * p.lddo;
 
-    stage<KS>(Qs, Qt, Q, p.ldq, 0, p.Sq, p.hd, head_off);
-    stage<KS>(DOs, DOt, DO, p.lddo, 0, p.Sq, p.hd, head_off);
-    stage<KS>(nullptr, Kt, K, p.ldk, 0, p.Sk, p.hd, head_off);
+    stage<KS>(Qs, nullptr, Q, p.ldq, 0, p.Sq, p.hd, head_off);
+    stage<KS>(DOs, nullptr, DO, p.lddo, 0, p.Sq, p.hd, head_off);
+    stage<KS>(Ks, nullptr, K, p.ldk, 0, p.Sk, p.hd, head_off);
     {   // delta = rowsum(dO * O) and lse of query `item`
         const bool qa = item < p.Sq;
         bf16x8 dof[KS], of[KS];
@@ -434,8 +436,8 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(Params p) {
         f32x4 dk[D16], dv[D16];
 #pragma unroll
         for (int dm = 0; dm < D16; ++dm) { dk[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        tile_accumulate<KS, D16>(dv, DOt, sc, x, g);
-        tile_accumulate<KS, D16>(dk, Qt, dp, x, g);
+        tile_accumulate<KS, D16>(dv, DOs, sc, x, g);
+        tile_accumulate<KS, D16>(dk, Qs, dp, x, g);
         if (kactive) {
             bf16_t* DK = reinterpret_cast<bf16_t*>(p.dk) + p.bsk * p.lddk;
             bf16_t* DV = reinterpret_cast<bf16_t*>(p.dv) + p.bsk * p.lddv;
@@ -451,18 +453,22 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(Params p) {
     f32x4 dq[D16];
 #pragma unroll
     for (int dm = 0; dm < D16; ++dm) dq[dm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const int q = x >> 2, pp = x & 3;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(DSs + item * DS_PITCH + (32 * s2 + 8 * g) * 2);
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(DSs + item * DS_PITCH + (32 * s2 + 8 * g) * 2);
+            const char* row_lo = Ks + (32 * s2 + 8 * g + q) * Geo<KS>::PR + 8 * pp;      // keys 32 s2 + 8 g .. +3
+            const char* row_hi = row_lo + 4 * Geo<KS>::PR;                                 // keys .. +4 .. +7
 #pragma unroll
-        for (int dm = 0; dm < D16; ++dm) {
-            const char* base = Kt + (16 * dm + x) * Geo<KS>::PT + (32 * s2 + 8 * g) * 2;
-            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(base);
-            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(base + 8);
-            bf16x8 a;
+            for (int dm = 0; dm < D16; ++dm) {
+                const bf16x4 lo = lds_tr4(row_lo + 32 * dm);
+                const bf16x4 hi = lds_tr4(row_hi + 32 * dm);
+                bf16x8 a;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
-            dq[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag, dq[dm], 0, 0, 0);
+                for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
+                dq[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag, dq[dm], 0, 0, 0);
+            }
         }
     }
     if (item < p.Sq) {
@@ -474,16 +480,16 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(Params p) {
 
 template <int KS, int D16>
 int launch(int which, const Params& p, hipStream_t s) {
-    const size_t row = Geo<KS>::ROW_BYTES, tr = Geo<KS>::TR_BYTES;
+    const size_t row = Geo<KS>::ROW_BYTES;
     if (which == 0) {
         dim3 grid((p.Sq + TILE - 1) / TILE, p.B * p.H);
-        hipLaunchKernelGGL((fwd_kernel<KS, D16>), grid, dim3(256), row + tr + TILE * 4, s, p);
+        hipLaunchKernelGGL((fwd_kernel<KS, D16>), grid, dim3(256), 2 * row + TILE * 4, s, p);
     } else if (which == 1) {
         dim3 grid((p.Sq + TILE - 1) / TILE, p.B * p.H);
-        hipLaunchKernelGGL((bwd_dq_kernel<KS, D16>), grid, dim3(256), 2 * row + tr + TILE * 4, s, p);
+        hipLaunchKernelGGL((bwd_dq_kernel<KS, D16>), grid, dim3(256), 2 * row + TILE * 4, s, p);
     } else if (which == 3) {
         static bool configured = false;
-        const size_t lds = 2 * row + 3 * tr + TILE * (TILE * 2 + 16) + 2 * TILE * 4;
+        const size_t lds = 3 * row + TILE * (TILE * 2 + 16) + 2 * TILE * 4;
         if (lds > 64 * 1024 && !configured) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel<KS, D16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -493,7 +499,7 @@ int launch(int which, const Params& p, hipStream_t s) {
         hipLaunchKernelGGL((bwd_fused_kernel<KS, D16>), dim3(1, p.B * p.H), dim3(256), lds, s, p);
     } else {
         static bool configured = false;        // hd = 128: 2 x 17 KiB + 2 x 17 KiB + stats > 64 KiB
-        const size_t lds = 2 * row + 2 * tr + 2 * TILE * 4;
+        const size_t lds = 2 * row + 2 * TILE * 4;
         if (lds > 64 * 1024 && !configured) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkv_kernel<KS, D16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
