@@ -97,10 +97,9 @@ class Stepper:
             self.opt.zero_grad()
             self.pending_update = False
 
-    def _encode_async(self, first=False):
+    def _encode_async(self):
         main = torch.cuda.current_stream()
-        if first:
-            self.side.wait_stream(main)                          # pixels / frozen weights are resident (set-up work on main)
+        self.side.wait_stream(main)                              # starts behind what is queued on main (AdamW of step i-1)
         with torch.cuda.stream(self.side):
             emb = self.vit.encode_image(self.batch["pixel_values"])
             ev = torch.cuda.Event()
@@ -114,16 +113,16 @@ class Stepper:
             emb = self.vit.encode_image(b["pixel_values"])
         else:
             if self.next_emb is None:
-                self._encode_async(first=True)                   # pipeline fill (first step only)
+                self._encode_async()                             # pipeline fill (first step only)
             emb, ready = self.next_emb, self.next_ready
             torch.cuda.current_stream().wait_event(ready)
         self._apply_update()                                     # AdamW of the previous step
+        if self.side is not None:
+            # batch i+1's encode beside the LM FORWARD of batch i (its N = 3840 / 5120 GEMMs leave CUs idle; beside the
+            # backward, whose 128 x 80 tiles fill every CU, the two streams only slow each other down: measured)
+            self._encode_async()
         out = self.model(question_tokens=b["input_ids"], prefix=emb, question_mask=b["attention_mask"], labels=b["labels"],
                          pad_token_id=self.pad, question_lengths=b["question_lengths"])
-        if self.side is not None:
-            # batch i+1's encode, enqueued behind the LM forward so that the main stream never waits for the host to
-            # enqueue the ~100 ViT kernels; it runs beside the LM backward of batch i (it depends on nothing trainable)
-            self._encode_async()
         out.loss.backward()
         self.sync.start()
         self.pending_update = True
