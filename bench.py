@@ -235,7 +235,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--cpu-baseline-samples", type=int, default=32, help="0 disables the CPU baseline leg")
+    ap.add_argument("--cpu-baseline-samples", type=int, default=64, help="0 disables the CPU baseline leg (default: one whole step of the workload, ~10 s)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the CLIP encode on the main stream (no cross-step pipelining)")
     ap.add_argument("--no-fewshot", action="store_true", help="skip the few-shot generate leg (metric M2, reported under 'extra')")

@@ -271,6 +271,16 @@ def test_fewshot_generate_matches_oracle_fp32(arch, fixture, use_cache):
     got = model.generate_fewshot(tok, prefix, mask, num_shots=n_img - 1, special_token_id=special, max_length=5,
                                  pad_token_id=pad, eos_token_id=None, use_cache=use_cache)
     assert got == want
+    # ensembling over two "permutations" of the in-context images: per-token log-probs feed the sequence scores
+    # (few_shot_vqa_executor.py:293-332); permuting the first two images changes the prompt, the selection is per question
+    from eavqa_amd.utils import ensembling
+    perms = [prefix, prefix[:, [1, 0, 2]]]
+    runs = [model.generate_fewshot(tok, p_, mask, num_shots=n_img - 1, special_token_id=special, max_length=5, pad_token_id=pad,
+                                   eos_token_id=None, use_cache=use_cache, output_scores=True) for p_ in perms]
+    assert runs[0][0] == want and tuple(runs[0][1].shape) == (B, 5) and bool((runs[0][1] <= 0).all())
+    best = ensembling.generate_from_ensembles(lambda i: runs[i], 2)
+    sc = np.stack([ensembling.sequence_scores(r[0], r[1]) for r in runs], 1)
+    assert best == [runs[int(np.argmax(sc[j]))][0][j] for j in range(B)]
     bad = tok.clone(); bad[0, 0] = 3; bad[0, 1] = 4     # row 0 loses a sentinel (it sat at index 0)
     if (bad[0] > special - n_img).sum() != n_img:
         with pytest.raises(ValueError, match="sentinel"):
