@@ -5,6 +5,8 @@ float32 mode must reproduce the reference's fp32 CPU logits/loss/grads to <= 1e-
 assert 2e-4 on the tiny models) and its generated ids exactly.  bfloat16 mode (bf16 operands, fp32
 accumulation and fp32 residual stream) is held to a stated looser tolerance.
 """
+import math
+
 import numpy as np
 import pytest
 import torch
@@ -340,3 +342,43 @@ def test_edge_shapes_match_oracle_fp32(arch, B, Tt, lens):
     for k, p in model.clip_project.named_parameters():
         want = mapper[k].grad
         assert (p.grad.cpu() - want).abs().max().item() <= 2e-4 * max(1.0, want.abs().max().item()), k
+
+
+def test_full_size_cfg2_properties_bf16():
+    """BASELINE configs[1] at its real size (GPT-2-large, 36 layers, E = 1280, MLP mapper 512 -> 6400 -> 12800, bf16; batch 16
+    of the 64 to keep the test short) through size-independent properties, since the CPU oracle cannot run it in seconds:
+    the packed and the padded training step agree on loss and mapper gradients, two identical steps are bitwise equal,
+    the gradient is linear in the upstream scale, and cached / uncached greedy decoding agree on the first token."""
+    from eavqa_amd.data.synthetic import cc_batch
+    from eavqa_amd.models.clipcap import ClipCaptionPrefix
+    from eavqa_amd.models.lm import FrozenCausalLM, LMConfig, KNOWN_CONFIGS, random_init_state_dict
+    cfg = LMConfig.from_hf_dict(KNOWN_CONFIGS["gpt2-large"])
+    lm = FrozenCausalLM(cfg, random_init_state_dict(cfg, 2021, DEV), torch.bfloat16, DEV)
+    torch.manual_seed(2021)
+    model = ClipCaptionPrefix(prefix_length=10, prefix_size=512, mapping_type="mlp", lm=lm, dtype=torch.bfloat16, device=DEV).train()
+    b = cc_batch(16, cfg.vocab, cfg.eos_token_id, max_len=32, seed=7, device=DEV, with_pixels=False, embed_dim=512)
+    kw = dict(question_tokens=b["input_ids"], prefix=b["clip_embeddings"], question_mask=b["attention_mask"], labels=b["labels"],
+              pad_token_id=cfg.eos_token_id)
+
+    def step(pack, scale=1.0):
+        model.pack_padding = pack
+        model.clip_project.zero_grad(set_to_none=True)
+        out = model(**kw)
+        (out.loss * scale).backward()
+        return out.loss.item(), {k: p.grad.clone() for k, p in model.clip_project.named_parameters()}
+
+    l_pack, g_pack = step(True)
+    l_pad, g_pad = step(False)
+    assert math.isfinite(l_pack) and abs(l_pack - l_pad) <= 2e-2 * abs(l_pad)
+    for k in g_pad:
+        den = g_pad[k].abs().max().item()
+        assert (g_pack[k] - g_pad[k]).abs().max().item() <= 5e-2 * den, k
+    l2, g2 = step(True)
+    assert l2 == l_pack and all(torch.equal(g2[k], g_pack[k]) for k in g2)          # fixed-order reductions everywhere
+    _, g3 = step(True, scale=4.0)
+    for k in g3:
+        assert (g3[k] - 4.0 * g_pack[k]).abs().max().item() <= 2e-2 * 4.0 * g_pack[k].abs().max().item(), k
+    model.eval()
+    gen = dict(question_tokens=b["input_ids"][:4, :8], prefix=b["clip_embeddings"][:4], question_mask=b["attention_mask"][:4, :8],
+               max_length=1, pad_token_id=cfg.eos_token_id, eos_token_id=None)
+    assert model.generate(use_cache=True, **gen) == model.generate(use_cache=False, **gen)
