@@ -69,9 +69,11 @@ def build_workload(name, dtype, device, rank):
     opt = FusedAdamW(model.clip_project.flat, lr=1e-4)
     pad = lcfg.eos_token_id
     batch = cc_batch(w["batch"], lcfg.vocab, pad, image_size=vcfg.image, max_len=w["text_len"], seed=2021 + rank, device="cpu")
-    lengths = batch["attention_mask"].sum(1).tolist()      # host-side metadata of the collate (caption lengths)
+    lengths = batch["attention_mask"].sum(1).tolist()      # host-side metadata of the collate (caption lengths,
+    label_count = int((batch["labels"] != -100).sum())     # number of scored positions)
     batch = {k: v.to(device) for k, v in batch.items()}
     batch["question_lengths"] = lengths
+    batch["label_count"] = label_count
     return w, vcfg, lcfg, vit, model, opt, batch, pad
 
 
@@ -122,7 +124,7 @@ class Stepper:
             # backward, whose 128 x 80 tiles fill every CU, the two streams only slow each other down: measured)
             self._encode_async()
         out = self.model(question_tokens=b["input_ids"], prefix=emb, question_mask=b["attention_mask"], labels=b["labels"],
-                         pad_token_id=self.pad, question_lengths=b["question_lengths"])
+                         pad_token_id=self.pad, question_lengths=b["question_lengths"], label_count=b["label_count"])
         out.loss.backward()
         self.sync.start()
         self.pending_update = True

@@ -37,6 +37,8 @@ SIGNATURES = {
     "eavqa_build_row_plan": [i32, i32, i32, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr],
     "eavqa_copy_rows": [i32, i32, i32, i32, ptr, i64, i64, ptr, i64, i64, i64, ptr],
     "eavqa_transpose": [i32, i32, i32, ptr, i64, ptr, i64, ptr],
+    "eavqa_select_rows": [i32, ptr, i32, ptr, ptr, ptr, ptr],
+    "eavqa_move_rows": [i32, i32, i32, i32, ptr, i64, ptr, ptr, i64, ptr],
     "eavqa_l2_normalize_rows": [i32, i32, ptr, i64, ptr],
     "eavqa_topk_rows": [i32, i32, ptr, i64, i32, ptr, ptr, ptr],
     "eavqa_gemm_splitk_plan": [i32, i32, i32],

@@ -273,6 +273,47 @@ __global__ __launch_bounds__(256) void transpose_kernel(int rows, int cols, cons
         if (c0 + i < cols && r0 + tx < rows) dst[(int64_t)(c0 + i) * ldd + r0 + tx] = tile[tx][i];
 }
 
+// ---- scored rows: only rows that carry a label reach the lm_head (2 E V FLOP per row forward, the same again for its
+// dgrad; on Conceptual-Captions batches a third of the packed rows - the prefix and the last token of every caption -
+// carry none).  One 1024-thread workgroup compacts the row numbers in order (ballot + popcount per wave, scan over the
+// 16 waves per chunk), so the result does not depend on scheduling.
+__global__ __launch_bounds__(1024) void select_rows_kernel(int M, const int64_t* __restrict__ row_labels, int cap,
+                                                           int32_t* __restrict__ sel_idx, int64_t* __restrict__ sel_labels,
+                                                           int32_t* __restrict__ count) {
+    __shared__ int wave_n[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < M; r0 += 1024) {
+        const int r = r0 + tid;
+        const int64_t lab = r < M ? row_labels[r] : -100;
+        const bool keep = lab >= 0;
+        const unsigned long long bal = __ballot(keep);
+        if (lane == 0) wave_n[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_n[w];
+        const int pos = off + __popcll(bal & ((1ull << lane) - 1ull));
+        if (keep && pos < cap) { sel_idx[pos] = r; sel_labels[pos] = lab; }
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_n[w]; base += t; }
+        __syncthreads();
+    }
+    if (tid == 0 && count) count[0] = base;
+}
+
+// dst[i, :] = src[idx[i], :] (gather) or dst[idx[i], :] = src[i, :] (scatter), 16-byte vectors
+template <typename T, bool SCATTER>
+__global__ __launch_bounds__(256) void move_rows_kernel(int cols, const T* __restrict__ src, int64_t lds, const int32_t* __restrict__ idx,
+                                                        T* __restrict__ dst, int64_t ldd) {
+    const int i = blockIdx.x, j = idx[i];
+    const T* x = src + (int64_t)(SCATTER ? i : j) * lds;
+    T* y = dst + (int64_t)(SCATTER ? j : i) * ldd;
+    constexpr int V = 16 / sizeof(T);
+    for (int c = threadIdx.x * V; c < cols; c += 256 * V) *reinterpret_cast<uint4*>(y + c) = *reinterpret_cast<const uint4*>(x + c);
+}
+
 __global__ void zero_kernel(int n, float* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = 0.f;
@@ -303,6 +344,34 @@ extern "C" int eavqa_copy_rows(int dtype, int B, int S, int cols, const void* sr
         hipLaunchKernelGGL(copy_rows_kernel<bf16_t>, dim3(B * S), dim3(256), 0, s, S, cols, (const bf16_t*)src, lds, src_batch_rows,
                            (bf16_t*)dst, ldd, dst_batch_rows, dst_row0);
     else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_select_rows(int M, const int64_t* row_labels, int capacity, int32_t* sel_idx, int64_t* sel_labels, int32_t* count,
+                                 void* stream) {
+    if (M <= 0 || capacity < 0 || !row_labels || !sel_idx || !sel_labels) return EAVQA_E_ARG;
+    hipLaunchKernelGGL(select_rows_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), M, row_labels, capacity, sel_idx,
+                       sel_labels, count);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_move_rows(int dtype, int scatter, int n, int cols, const void* src, int64_t ld_src, const int32_t* idx, void* dst,
+                               int64_t ld_dst, void* stream) {
+    if (n < 0 || cols <= 0 || !src || !idx || !dst) return EAVQA_E_ARG;
+    if (n == 0) return EAVQA_OK;
+    const int vec = dtype == EAVQA_BF16 ? 8 : 4;
+    if (dtype != EAVQA_BF16 && dtype != EAVQA_F32) return EAVQA_E_DTYPE;
+    if (cols % vec || ld_src % vec || ld_dst % vec || !eavqa_aligned16(src) || !eavqa_aligned16(dst)) return EAVQA_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_BF16) {
+        if (scatter) hipLaunchKernelGGL((move_rows_kernel<bf16_t, true>), dim3(n), dim3(256), 0, s, cols, (const bf16_t*)src, ld_src, idx, (bf16_t*)dst, ld_dst);
+        else hipLaunchKernelGGL((move_rows_kernel<bf16_t, false>), dim3(n), dim3(256), 0, s, cols, (const bf16_t*)src, ld_src, idx, (bf16_t*)dst, ld_dst);
+    } else {
+        if (scatter) hipLaunchKernelGGL((move_rows_kernel<float, true>), dim3(n), dim3(256), 0, s, cols, (const float*)src, ld_src, idx, (float*)dst, ld_dst);
+        else hipLaunchKernelGGL((move_rows_kernel<float, false>), dim3(n), dim3(256), 0, s, cols, (const float*)src, ld_src, idx, (float*)dst, ld_dst);
+    }
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }

@@ -330,7 +330,7 @@ class _PrefixLMLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prefix_rows, lm: FrozenCausalLM, src, pos, mask, labels, B, S, holder):
         out = lm.forward(prefix_rows, src, pos, mask, B, S, labels=labels, save=True, pack=holder.pop("pack", False),
-                         lengths=holder.pop("lengths", None))
+                         lengths=holder.pop("lengths", None), n_scored=holder.pop("n_scored", None))
         ctx.lm, ctx.tape, ctx.n_rows = lm, out["tape"], prefix_rows.shape[0]
         holder.update(out)
         return out["loss"].view(())
@@ -348,14 +348,20 @@ class _Output:
     ``.logits`` [B, L+T, V] float32 is assembled on first access: after a packed forward the padded positions (whose
     reference logits are never used: no loss, never attended) read as zeros."""
 
-    def __init__(self, loss, rows_logits, B, S, V, flat_index=None):
+    def __init__(self, loss, rows_logits, B, S, V, flat_index=None, scored_only=None):
         self.loss = loss
         self._lg, self._B, self._S, self._V, self._flat = rows_logits, B, S, V, flat_index
+        self._scored_only = scored_only      # (lm, hidden): only the scored rows went through the lm_head during the step
         self._full = None
 
     @property
     def logits(self):
         if self._full is None:
+            if self._scored_only is not None:
+                lm, hidden = self._scored_only
+                with torch.no_grad():
+                    self._lg = lm._head(hidden)          # on demand: the logits of every packed row
+                self._scored_only = None
             if self._flat is None:
                 self._full = self._lg.view(self._B, self._S, -1)[:, :, :self._V]
             else:
@@ -399,6 +405,8 @@ class ClipCaptionModel(nn.Module):
             self.clip_project = MLP((prefix_size, (E * prefix_length) // 2, E * prefix_length), device=device, dtype=dtype)
         else:
             self.clip_project = TransformerMapper(prefix_size, E, prefix_length, clip_length, num_layers, device=device, dtype=dtype)
+        # with a host-side label count the packed training forward runs the lm_head on the scored rows only
+        self.score_labeled_rows_only = True
         # training forward drops padded positions before the first GEMM (exact for loss / gradients / attended logits)
         self.pack_padding = True
 
@@ -421,10 +429,14 @@ class ClipCaptionModel(nn.Module):
 
     # -- training forward --------------------------------------------------------------------
     def forward(self, question_tokens: Tensor, prefix: Tensor, question_mask: Optional[Tensor] = None,
-                labels: Optional[Tensor] = None, pad_token_id: Optional[int] = None, question_lengths=None):
+                labels: Optional[Tensor] = None, pad_token_id: Optional[int] = None, question_lengths=None,
+                label_count: Optional[int] = None):
         """``forward`` clipcap.py:290-342 -> object with ``.loss`` (0-d, differentiable w.r.t. the mapper)
         and ``.logits`` [B, L+T, V] float32.  ``question_lengths`` (optional host ints: attended tokens per row,
-        i.e. ``question_mask.sum(1)``) spares the packed path one device->host read."""
+        i.e. ``question_mask.sum(1)``) spares the packed path one device->host read.  ``label_count`` (optional host int,
+        ``(labels != -100).sum()``; taken from ``labels`` itself when that is a host tensor) lets the packed training
+        path run the lm_head on the scored positions only: loss and gradients are unchanged; ``.logits``, if read, is
+        computed on demand for all packed rows."""
         dev = self.device_
         B, T = question_tokens.shape
         L = self.prefix_length
@@ -445,9 +457,12 @@ class ClipCaptionModel(nn.Module):
                         question_lengths = (question_mask != 0).sum(1).tolist()     # host tensor: free
                 if question_lengths is not None:
                     lengths = [L + int(n) for n in question_lengths]
-            holder: dict = {"pack": pack, "lengths": lengths}
+            if pack and label_count is None and not labels.is_cuda:
+                label_count = int((labels != -100).sum())                           # host tensor: free
+            holder: dict = {"pack": pack, "lengths": lengths, "n_scored": label_count if (pack and self.score_labeled_rows_only) else None}
             loss = _PrefixLMLoss.apply(rows, self.gpt, src, pos, mask, full, B, S, holder)
-            return _Output(loss, holder["logits"], B, S, self.gpt.vocab, holder["flat_index"] if pack else None)
+            scored_only = (self.gpt, holder["hidden"]) if holder.get("sel") is not None else None
+            return _Output(loss, holder["logits"], B, S, self.gpt.vocab, holder["flat_index"] if pack else None, scored_only)
         lg = self.gpt.forward(rows, src, pos, mask, B, S, logits="all")["logits"]
         return _Output(None, lg, B, S, self.gpt.vocab)
 

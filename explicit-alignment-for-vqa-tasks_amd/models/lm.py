@@ -252,7 +252,7 @@ class FrozenCausalLM:
     # ---------------------------------------------------------------- forward
     def forward(self, prefix_rows: Optional[Tensor], src: Tensor, pos: Tensor, mask: Tensor, B: int, S: int, *,
                 labels: Optional[Tensor] = None, save: bool = False, logits: str = "none", pack: bool = False,
-                lengths=None):
+                lengths=None, n_scored: Optional[int] = None):
         """Run the decoder over ``B`` rows of ``S`` positions.
 
         ``src/pos/mask``: int32 [B,S] from ``ops.build_prefix_rows`` / ``build_fewshot_rows``;
@@ -262,6 +262,10 @@ class FrozenCausalLM:
         (host ints, attended positions per sample) saves the one device->host read of the packed row count.
         Returns a dict with ``loss``/``count`` (when labels), ``logits`` ([rows or B, vpad] fp32; with ``pack`` also
         ``flat_index`` mapping packed rows to b*S+s) and, when ``save``, the tape for :meth:`backward`.
+        ``n_scored`` (host int, with ``pack`` and ``labels``): the number of positions that carry a label - exactly
+        ``(labels != -100).sum()`` when every label has a predecessor position, as behind a prefix; the collate has it on
+        the host.  Then only those rows go through the lm_head and its dgrad (``out["logits"]`` holds just them, ``sel``
+        their packed row numbers).
         """
         c, T = self.cfg, self.dtype
         E, H, hd = c.n_embd, c.n_head, c.head_dim
@@ -314,14 +318,19 @@ class FrozenCausalLM:
             hf = ops.layernorm_fwd(x, self.lnf_g, self.lnf_b, c.eps, T)
         out["hidden"] = hf
         if labels is not None or logits == "all":
-            lg = self._head(hf)
-            out["logits"] = lg
-            if labels is not None:
+            sel = None
+            if pack and labels is not None and n_scored is not None and logits != "all" and 0 < n_scored < M:
+                sel, ce_labels, _ = ops.select_rows(row_labels, int(n_scored))
+                lg = self._head(ops.gather_rows(hf, sel))
+            else:
+                lg = self._head(hf)
                 ce_labels = row_labels if pack else labels
+            out["logits"], out["sel"] = lg, sel
+            if labels is not None:
                 loss, count, row_lse = ops.ce_fwd(lg, ce_labels, self.vocab)
                 out["loss"], out["count"] = loss, count
                 if save:
-                    out["tape"] = dict(layers=tape, x_last=x, meanf=meanf, rstdf=rstdf, logits=lg, labels=ce_labels,
+                    out["tape"] = dict(layers=tape, x_last=x, meanf=meanf, rstdf=rstdf, logits=lg, labels=ce_labels, sel=sel,
                                        row_lse=row_lse, count=count, src=src, mask=attn_mask, cu=cu, B=B, S=S, M=M)
         return out
 
@@ -349,7 +358,9 @@ class FrozenCausalLM:
         # the residual-stream gradient lives in fp32 (dx); each LayerNorm backward also emits the copy in the
         # compute dtype that the next dgrad GEMM consumes as its A operand (no separate cast pass)
         dlog = ops.ce_bwd(tape["logits"], tape["labels"], self.vocab, tape["row_lse"], tape["count"], gloss, T, self.vpad)
-        dhf = ops.gemm(dlog, self.head_t)                                   # [M,E]
+        dhf = ops.gemm(dlog, self.head_t)                                   # [M,E] (or [n_scored,E])
+        if tape.get("sel") is not None:
+            dhf = ops.scatter_rows(dhf, tape["sel"], M)                      # rows without a label get no gradient here
         dxT = torch.empty((M, E), device=self.device, dtype=T) if lowp else None
         dx = ops.layernorm_bwd(tape["x_last"], dhf, self.lnf_g, tape["meanf"], tape["rstdf"], lowp_out=dxT)
         for L, (x, mean1, rstd1, qkv, ctx, lse, x1, mean2, rstd2, u) in zip(reversed(self.layers), reversed(tape["layers"])):

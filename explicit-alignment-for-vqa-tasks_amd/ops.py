@@ -340,3 +340,26 @@ def topk_rows(scores: Tensor, k: int):
     idx = torch.empty((rows, k), device=scores.device, dtype=torch.int64)
     call("eavqa_topk_rows", rows, cols, _p(scores), _ld(scores), int(k), _p(val), _p(idx), _stream())
     return val, idx
+
+
+def select_rows(row_labels: Tensor, capacity: int):
+    """(sel_idx int32 [capacity], sel_labels int64 [capacity], count int32 [1]) of the rows with a label >= 0, in order."""
+    M = row_labels.shape[0]
+    idx = torch.zeros(capacity, device=row_labels.device, dtype=torch.int32)
+    lab = torch.full((capacity,), -100, device=row_labels.device, dtype=torch.int64)
+    cnt = torch.zeros(1, device=row_labels.device, dtype=torch.int32)
+    call("eavqa_select_rows", M, _p(row_labels), int(capacity), _p(idx), _p(lab), _p(cnt), _stream())
+    return idx, lab, cnt
+
+
+def gather_rows(src: Tensor, idx: Tensor) -> Tensor:
+    out = torch.empty((idx.shape[0], src.shape[1]), device=src.device, dtype=src.dtype)
+    call("eavqa_move_rows", dtype_id(src.dtype), 0, idx.shape[0], src.shape[1], _p(src), _ld(src), _p(idx), _p(out), _ld(out), _stream())
+    return out
+
+
+def scatter_rows(src: Tensor, idx: Tensor, rows: int) -> Tensor:
+    """[rows, cols] zeros with out[idx[i]] = src[i]."""
+    out = torch.zeros((rows, src.shape[1]), device=src.device, dtype=src.dtype)
+    call("eavqa_move_rows", dtype_id(src.dtype), 1, idx.shape[0], src.shape[1], _p(src), _ld(src), _p(idx), _p(out), _ld(out), _stream())
+    return out

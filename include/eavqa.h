@@ -176,6 +176,14 @@ int eavqa_build_row_plan(int B, int S, int pack, const int32_t* mask, const int6
  * projection rows (the reference re-runs the whole sequence instead, clipcap.py:414-419). cols % 4 == 0. */
 int eavqa_copy_rows(int dtype, int B, int S, int cols, const void* src, int64_t lds, int64_t src_batch_rows,
                     void* dst, int64_t ldd, int64_t dst_batch_rows, int64_t dst_row0, void* stream);
+/* Rows that carry a label (row_labels[r] >= 0, as produced by eavqa_build_row_plan): their row numbers, in order, into
+ * sel_idx[0..capacity) and their labels into sel_labels; count[0] (optional) = how many there are.  Only these rows go
+ * through the lm_head (HF computes all B*S rows of logits and ignores the rest in the loss, loss_utils.py:32-46). */
+int eavqa_select_rows(int M, const int64_t* row_labels, int capacity, int32_t* sel_idx, int64_t* sel_labels, int32_t* count,
+                      void* stream);
+/* scatter = 0: dst[i, :] = src[idx[i], :];  scatter = 1: dst[idx[i], :] = src[i, :]  for i < n (`dtype`, cols % 8 (bf16) / 4). */
+int eavqa_move_rows(int dtype, int scatter, int n, int cols, const void* src, int64_t ld_src, const int32_t* idx, void* dst,
+                    int64_t ld_dst, void* stream);
 /* dst[c, r] = src[r, c] (`dtype` -> `dtype`): the k-contiguous copy of a trainable [N,K] weight that its dgrad GEMM streams
  * (the frozen weights get theirs once at load; the MLP mapper's second Linear needs a fresh one per step). */
 int eavqa_transpose(int dtype, int rows, int cols, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, void* stream);

@@ -207,17 +207,26 @@ def test_packed_and_padded_training_steps_agree_fp32():
     model = build_model(z, "gpt2", "mlp", torch.float32).train()
     args = dict(question_tokens=T(z["ids"]), prefix=T(z["prefix"]), question_mask=T(z["mask"]), labels=T(z["labels"]))
     res = {}
+    n_lab = int((T(z["labels"]) != -100).sum())
     for name, pack, kw in (("padded", False, {}), ("packed_host_lengths", True, {}),
-                           ("packed_device_lengths", True, dict(question_mask=T(z["mask"]).to(DEV)))):
+                           ("packed_device_lengths", True, dict(question_mask=T(z["mask"]).to(DEV))),
+                           ("packed_all_rows_scored", True, dict(labels=T(z["labels"]).to(DEV))),          # device labels: no count
+                           ("packed_count_hint", True, dict(labels=T(z["labels"]).to(DEV), label_count=n_lab)),
+                           ("packed_count_overestimate", True, dict(labels=T(z["labels"]).to(DEV), label_count=n_lab + 3))):
         model.pack_padding = pack
         model.clip_project.zero_grad(set_to_none=True)
         out = model(**{**args, **kw})
         out.loss.backward()
         res[name] = (out.loss.item(), {k: p.grad.clone() for k, p in model.clip_project.named_parameters()})
-    for name in ("packed_host_lengths", "packed_device_lengths"):
+    for name in ("packed_host_lengths", "packed_device_lengths", "packed_all_rows_scored", "packed_count_hint", "packed_count_overestimate"):
         assert abs(res[name][0] - res["padded"][0]) <= 1e-6
         for k, g in res["padded"][1].items():
             assert torch.allclose(res[name][1][k], g, atol=1e-6, rtol=1e-5), (name, k)
+    # .logits after a scored-rows-only forward is computed on demand and equals the all-rows packed result
+    model.pack_padding = True
+    a = model(**{**args, "labels": T(z["labels"]).to(DEV)}).logits.cpu()             # every packed row through the head
+    b = model(**{**args, "label_count": n_lab}).logits.cpu()
+    assert torch.equal(a, b)
 
 
 def _oracle_fewshot_generate(sd, cfg, mapper, L, tokens, prefix, mask, n_img, special, max_length, pad, eos):

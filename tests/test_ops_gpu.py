@@ -601,3 +601,24 @@ def test_layernorm_splitk(ops, dtype, rows, cols, ks):
                              bias=bias.to(DEV) if ks else None, x_out=xo)
     assert (xo.cpu() - xs).abs().max().item() <= 1e-5
     assert (y.float().cpu() - want).abs().max().item() <= tol(dtype, 1.0) * max(1.0, want.abs().max().item())
+
+
+def test_select_gather_scatter_rows(ops):
+    g = torch.Generator().manual_seed(4)
+    M, E = 3001, 64
+    labels = torch.where(torch.rand(M, generator=g) < 0.6, torch.randint(0, 500, (M,), generator=g), torch.full((M,), -100))
+    want = torch.nonzero(labels >= 0).flatten()
+    idx, lab, cnt = ops.select_rows(labels.to(DEV), len(want) + 5)          # over-estimated capacity: the tail stays (0, -100)
+    assert cnt.item() == len(want)
+    assert torch.equal(idx.cpu()[:len(want)].long(), want) and torch.equal(lab.cpu()[:len(want)], labels[want])
+    assert (idx.cpu()[len(want):] == 0).all() and (lab.cpu()[len(want):] == -100).all()
+    idx2, _, cnt2 = ops.select_rows(labels.to(DEV), 10)                     # capacity below the count: first 10 only, count is still exact
+    assert torch.equal(idx2.cpu().long(), want[:10]) and cnt2.item() == len(want)
+    for dtype in (torch.float32, torch.bfloat16):
+        x = rnd(M, E, dtype=dtype, seed=5).to(DEV)
+        sel = idx[:len(want)].contiguous()
+        y = ops.gather_rows(x, sel)
+        assert torch.equal(y.cpu(), x.cpu()[want])
+        back = ops.scatter_rows(y, sel, M)
+        ref = torch.zeros(M, E, dtype=dtype); ref[want] = x.cpu()[want]
+        assert torch.equal(back.cpu(), ref)
