@@ -87,13 +87,18 @@ class ClipCapExecutor:
         ids = sample_batched["input_ids"].to(self.device)
         mask = sample_batched["attention_mask"].to(self.device)
         pad_id = self._pad_id()
+        label_count = None
         if "labels" in sample_batched and self.config.get("data_loader", {}).get("type", "") == "DataLoaderConceptualCaptions":
-            labels = sample_batched["labels"].to(self.device)
+            labels = sample_batched["labels"]
+            if not labels.is_cuda:
+                label_count = int((labels != -100).sum())       # the collate's tensor is on the host: counting is free
+            labels = labels.to(self.device)
         else:
             bos = getattr(self.tokenizer, "bos_token_id", None)
             labels = ops.build_labels(ids, 0, pad_id, -1 if bos is None else bos, mode=0)   # :134-150
         prefix = self._clip_embeddings(sample_batched)
-        out = self.model(question_tokens=ids, labels=labels, prefix=prefix, question_mask=mask, pad_token_id=pad_id)   # :165-171
+        out = self.model(question_tokens=ids, labels=labels, prefix=prefix, question_mask=mask, pad_token_id=pad_id,
+                         label_count=label_count)   # :165-171
         loss = out.loss
         for i, lr in enumerate(self.scheduler.get_last_lr() if self.scheduler else []):
             self.log(f"train/lr[{i}]", lr, prog_bar=True, on_step=True, logger=True)
