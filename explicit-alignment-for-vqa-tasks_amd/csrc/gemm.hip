@@ -736,20 +736,23 @@ int launch_shaped(const GemmParams& p, hipStream_t stream) {
 // test / experiment knob: 0 = choose by shape, 1 = never a shaped tile, else force SHAPES[id - 2]
 int g_shape_mode = 0;
 
-struct ShapeChoice { int bm, bn; int (*launch)(const GemmParams&, hipStream_t); };
+// `rate`: measured ns per 64-byte operand row and K-step (32) of one workgroup alone on a CU (K = 5120 probes and the
+// cfg2 shapes, tools/gemm_bench.py): the wider 8-wave tiles get closer to the MFMA / LDS limits and pay more per byte.
+struct ShapeChoice { int bm, bn; float rate; int (*launch)(const GemmParams&, hipStream_t); };
 const ShapeChoice SHAPES[5] = {
-    {128, 80, launch_shaped<4, 1, 2, 5>}, {128, 96, launch_shaped<4, 1, 2, 6>},
-    {256, 128, launch_shaped<4, 2, 4, 4>}, {256, 160, launch_shaped<4, 2, 4, 5>}, {256, 192, launch_shaped<4, 2, 4, 6>},
+    {128, 80, 1.17f, launch_shaped<4, 1, 2, 5>}, {128, 96, 1.20f, launch_shaped<4, 1, 2, 6>},
+    {256, 128, 1.15f, launch_shaped<4, 2, 4, 4>}, {256, 160, 1.23f, launch_shaped<4, 2, 4, 5>}, {256, 192, 1.39f, launch_shaped<4, 2, 4, 6>},
 };
+constexpr float RATE_FAST = 1.245f, RATE_BIG = 1.27f;
 
 // Modelled time (ns, without the launch) of a grid of bm x bn tiles: the fullest XCD's workgroups per CU (co-resident
 // ones share the CU's intake rate) x (operand bytes per K-step at that rate + the tile's epilogue).  Calibrated on MI355X
 // (128 x 128: 17.8 us at K = 1280, 51.9 us at K = 5120; 256 x 128 on 240 tiles: 29 us at K = 1280).
-inline float tile_cost(const GemmParams& p, int bm, int bn) {
+inline float tile_cost(const GemmParams& p, int bm, int bn, float rate) {
     const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + bn - 1) / bn;
     const GridPlan g = plan_grid(tiles_m, tiles_n, bm, bn);
     const float rounds = float((g.per_xcd + 31) / 32);
-    return rounds * (1.11f * (bm + bn) * (p.K / 32) + 0.25f * bm * bn);
+    return rounds * (rate * (bm + bn) * (p.K / 32) + 0.25f * bm * bn);
 }
 
 // ====================================================== bf16 big tiles ===
@@ -1177,12 +1180,12 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
             const bool big_ok = (K % GBK) == 0 && g_big_mode != 1;
             if (big_ok && g_big_mode == 2) return launch_big(p, s);
             // candidates in order of preference at equal cost: 128 x 128 (two workgroups per CU), 256 x 256, shaped tiles
-            float best = tile_cost(p, 128, 128);
+            float best = tile_cost(p, 128, 128, RATE_FAST);
             int pick = -1;                                   // -1 fast, -2 big, >= 0 SHAPES[pick]
-            if (big_ok && use_big(p)) { best = fminf(best, tile_cost(p, 256, 256)); pick = -2; }
+            if (big_ok && use_big(p)) { best = fminf(best, tile_cost(p, 256, 256, RATE_BIG)); pick = -2; }
             if (g_shape_mode != 1)
                 for (int i = 0; i < 5; ++i) {
-                    const float c = tile_cost(p, SHAPES[i].bm, SHAPES[i].bn);
+                    const float c = tile_cost(p, SHAPES[i].bm, SHAPES[i].bn, SHAPES[i].rate);
                     if (c < best * 0.95f) { best = c; pick = i; }
                 }
             if (pick >= 0) return SHAPES[pick].launch(p, s);
