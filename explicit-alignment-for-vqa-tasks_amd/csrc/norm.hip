@@ -23,18 +23,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int x_f32, int rows, int co
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nv = cols >> 2;
-    float4 v[NV];
+    float4 v[NV], gm[NV], bt[NV];
     float s = 0.f;
+    // gamma / beta are fetched together with the row: one memory round trip instead of two dependent ones
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
             v[i] = ldrow4<T>(x, (int64_t)row * ldx + 4 * c, x_f32);
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            gm[i] = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            bt[i] = beta ? *reinterpret_cast<const float4*>(beta + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
         } else {
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
     const float mu = wave_sum(s) / (float)cols;
     float q = 0.f;
 #pragma unroll
@@ -54,13 +58,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int x_f32, int rows, int co
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
-            float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
-            float4 b = beta ? *reinterpret_cast<const float4*>(beta + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 o;
-            o.x = (v[i].x - mu) * rs * g.x + b.x;
-            o.y = (v[i].y - mu) * rs * g.y + b.y;
-            o.z = (v[i].z - mu) * rs * g.z + b.z;
-            o.w = (v[i].w - mu) * rs * g.w + b.w;
+            o.x = (v[i].x - mu) * rs * gm[i].x + bt[i].x;
+            o.y = (v[i].y - mu) * rs * gm[i].y + bt[i].y;
+            o.z = (v[i].z - mu) * rs * gm[i].z + bt[i].z;
+            o.w = (v[i].w - mu) * rs * gm[i].w + bt[i].w;
             elem<T>::st4(y + (int64_t)row * ldy + 4 * c, o);
         }
     }
