@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
 }
 
 bool decode_supported(int dtype, int Sq, int Sk, int hd, const int32_t* cu, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo) {
-    return dtype == EAVQA_BF16 && Sq == 1 && !cu && hd % 8 == 0 && hd <= 128 && Sk <= 4096 && (ldq % 8 == 0) && (ldk % 8 == 0) &&
+    return dtype == EAVQA_BF16 && Sq == 1 && !cu && hd % 8 == 0 && hd <= 128 && Sk <= 3584 && (ldq % 8 == 0) && (ldk % 8 == 0) &&
            (ldv % 8 == 0) && (ldo % 8 == 0);
 }
 

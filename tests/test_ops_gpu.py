@@ -279,7 +279,7 @@ def test_attention_kv_cache_batch_stride(ops):
 
 
 @pytest.mark.parametrize("B,H,Sk,hd,masked", [(3, 5, 157, 80, True), (2, 8, 300, 128, False), (2, 4, 40, 64, True), (1, 3, 7, 32, False),
-                                              (32, 32, 160, 80, True)])
+                                              (32, 32, 160, 80, True), (1, 4, 3584, 64, False), (1, 4, 3600, 64, False)])
 def test_attention_decode_step(ops, B, H, Sk, hd, masked):
     """Sq = 1 in bf16 takes the decode kernel (4 heads per workgroup, K/V streamed once): cache with a batch stride, ragged
     masks, H not a multiple of 4."""
