@@ -75,16 +75,20 @@ __device__ __forceinline__ void load_bfrag(bf16x8 (&f)[KS], const bf16_t* src, i
     }
 }
 
-// acc[f] (f = 0..3, 16 register items each) = sum_d A_tile[item 16 f + (lane & 15)][d] * bfrag[d]
+// acc[f] (f = 0..3, 16 register items each) = sum_d A_tile[item 16 f + (lane & 15)][d] * bfrag[d]; only the first `nf`
+// fragments are computed (a ragged last tile: 257 = 4 x 64 + 1 ViT tokens leave 63 of 64 register items empty), the rest
+// read as zero
 template <int KS>
-__device__ __forceinline__ void tile_dot(f32x4 (&acc)[4], const char* rowmaj, const bf16x8 (&bf)[KS], int x, int g) {
+__device__ __forceinline__ void tile_dot(f32x4 (&acc)[4], const char* rowmaj, const bf16x8 (&bf)[KS], int x, int g, int nf = 4) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
         acc[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (f < nf) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowmaj + (16 * f + x) * Geo<KS>::PR + (32 * s + 8 * g) * 2);
-            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[s], acc[f], 0, 0, 0);
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowmaj + (16 * f + x) * Geo<KS>::PR + (32 * s + 8 * g) * 2);
+                acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[s], acc[f], 0, 0, 0);
+            }
         }
     }
 }
@@ -102,10 +106,12 @@ __device__ __forceinline__ bf16x4 lds_tr4(const char* p) {
 // accumulator-as-B trick: items 32 s2 + 4 g .. +3 and 32 s2 + 16 + 4 g .. +3) comes out of two transposing reads, so no
 // transposed copy of the tile is ever written.
 template <int KS, int D16>
-__device__ __forceinline__ void tile_accumulate(f32x4 (&out)[D16], const char* rowmaj, const f32x4 (&w)[4], int x, int g) {
+__device__ __forceinline__ void tile_accumulate(f32x4 (&out)[D16], const char* rowmaj, const f32x4 (&w)[4], int x, int g,
+                                                int nf = 4) {
     const int q = x >> 2, pp = x & 3;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
+        if (s2 == 1 && nf <= 2) break;                  // register items 32 .. 63 are all empty
         bf16x8 b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { b[r] = (bf16_t)w[2 * s2][r]; b[4 + r] = (bf16_t)w[2 * s2 + 1][r]; }
@@ -160,6 +166,7 @@ __global__ __launch_bounds__(256) void fwd_kernel(Params p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
     const int qi = q0 + wave * 16 + x;
     const bool active = qi < p.Sq;
+    const bool wave_has_query = q0 + wave * 16 < p.Sq;       // a wave without queries only helps staging the tiles
     const int off = p.Sk - p.Sq, head_off = h * p.hd;
     const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + p.bsq * p.ldq;
     const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + p.bsk * p.ldk;
@@ -182,8 +189,10 @@ __global__ __launch_bounds__(256) void fwd_kernel(Params p) {
         for (int c = threadIdx.x; c < TILE; c += 256)
             valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
         __syncthreads();
+        const int nf = min(4, (min(TILE, p.Sk - k0) + 15) >> 4);      // 16-key fragments of this tile that hold a key
+        if (wave_has_query) {
         f32x4 st[4];
-        tile_dot<KS>(st, Ks, qf, x, g);
+        tile_dot<KS>(st, Ks, qf, x, g, nf);
         float tmax = -FLT_MAX;
 #pragma unroll
         for (int f = 0; f < 4; ++f)
@@ -208,8 +217,9 @@ __global__ __launch_bounds__(256) void fwd_kernel(Params p) {
                 st[f][r] = pj;
                 lsum += pj;
             }
-        tile_accumulate<KS, D16>(acc, Vs, st, x, g);
+        tile_accumulate<KS, D16>(acc, Vs, st, x, g, nf);
         m = m_new;
+        }
     }
     const float l = group4_sum(lsum);
     if (active) {
