@@ -402,29 +402,32 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(Params p) {
     stage<KS>(Qs, nullptr, Q, p.ldq, 0, p.Sq, p.hd, head_off);
     stage<KS>(DOs, nullptr, DO, p.lddo, 0, p.Sq, p.hd, head_off);
     stage<KS>(Ks, nullptr, K, p.ldk, 0, p.Sk, p.hd, head_off);
-    {   // delta = rowsum(dO * O) and lse of query `item`
-        const bool qa = item < p.Sq;
-        bf16x8 dof[KS], of[KS];
-        load_bfrag<KS>(dof, DO, p.lddo, item, qa, p.hd, head_off, g);
-        load_bfrag<KS>(of, O, p.ldo, item, qa, p.hd, head_off, g);
+    // every tile is fetched from memory once: Q, dO, K as LDS images (whose rows also serve as this lane's fragments), V and
+    // O only as fragments
+    const bool qa = item < p.Sq, kactive = item < p.Sk;
+    bf16x8 vf[KS], of[KS];
+    load_bfrag<KS>(vf, V, p.ldv, item, kactive, p.hd, head_off, g);
+    load_bfrag<KS>(of, O, p.ldo, item, qa, p.hd, head_off, g);
+    const int64_t stat_at = ((int64_t)b * p.H + h) * p.stat_ld + item;
+    if (g == 0) stats[item] = qa ? p.lse[stat_at] : 0.f;
+    const bool kvalid = kactive && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + item] != 0);
+    __syncthreads();
+    bf16x8 kf[KS];
+    {
         float dsum = 0.f;
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
+        for (int s = 0; s < KS; ++s) {
+            kf[s] = *reinterpret_cast<const bf16x8*>(Ks + item * Geo<KS>::PR + (32 * s + 8 * g) * 2);
+            const bf16x8 dof = *reinterpret_cast<const bf16x8*>(DOs + item * Geo<KS>::PR + (32 * s + 8 * g) * 2);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dsum += (float)dof[s][j] * (float)of[s][j];
-        const float delta = group4_sum(dsum);
+            for (int j = 0; j < 8; ++j) dsum += (float)dof[j] * (float)of[s][j];
+        }
+        const float delta = group4_sum(dsum);        // rowsum(dO * O) of query `item`
         if (g == 0) {
-            const int64_t st = ((int64_t)b * p.H + h) * p.stat_ld + item;
-            stats[item] = qa ? p.lse[st] : 0.f;
             stats[TILE + item] = qa ? delta : 0.f;
-            if (qa) p.delta[st] = delta;
+            if (qa) p.delta[stat_at] = delta;
         }
     }
-    const bool kactive = item < p.Sk;
-    bf16x8 kf[KS], vf[KS];
-    load_bfrag<KS>(kf, K, p.ldk, item, kactive, p.hd, head_off, g);
-    load_bfrag<KS>(vf, V, p.ldv, item, kactive, p.hd, head_off, g);
-    const bool kvalid = kactive && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + item] != 0);
     __syncthreads();
 
     f32x4 sc[4], dp[4];
