@@ -55,6 +55,52 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int S, int V, const float* 
     }
 }
 
+// V <= 64 Ki: one 1024-thread workgroup per row keeps the whole row in registers (<= 64 values per thread): the row is
+// read from memory once, every load is in flight before the first use, one exp per element; max and sum are fixed-order
+// trees (wave shuffles, then the 16 wave results in order).
+constexpr int CE_T = 1024, CE_NPT = 64;
+__global__ __launch_bounds__(CE_T) void ce_fwd_row_kernel(int S, int V, const float* __restrict__ logits, int64_t ld,
+                                                          const int64_t* __restrict__ labels, float* __restrict__ row_loss,
+                                                          float* __restrict__ row_lse) {
+    __shared__ float red[16];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lab = shifted_label(labels, S, row);
+    if (lab < 0 || lab >= V) {
+        if (tid == 0) { row_loss[row] = 0.f; row_lse[row] = 0.f; }
+        return;
+    }
+    const float* x = logits + (int64_t)row * ld;
+    float v[CE_NPT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < CE_NPT; ++i) {
+        const int c = tid + CE_T * i;
+        v[i] = c < V ? x[c] : -INFINITY;
+    }
+#pragma unroll
+    for (int i = 0; i < CE_NPT; ++i) m = fmaxf(m, v[i]);
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    float M = red[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) M = fmaxf(M, red[w]);
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < CE_NPT; ++i) s += __expf(v[i] - M);          // exp(-inf) = 0 for the padding
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        const float lse = M + logf(tot);
+        row_lse[row] = lse;
+        row_loss[row] = lse - x[lab];
+    }
+}
+
 __global__ __launch_bounds__(1024) void ce_reduce_kernel(int rows, int S, const float* row_loss, const int64_t* labels,
                                                          int V, float* loss, float* count) {
     __shared__ float sl[1024], sc[1024];
@@ -158,7 +204,8 @@ extern "C" int eavqa_ce_fwd(int B, int S, int V, const float* logits, int64_t ld
     if (ld < V) return EAVQA_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rows = S > 0 ? B * S : B;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, s, S, V, logits, ld, labels, row_loss, row_lse);
+    if (V <= CE_T * CE_NPT) hipLaunchKernelGGL(ce_fwd_row_kernel, dim3(rows), dim3(CE_T), 0, s, S, V, logits, ld, labels, row_loss, row_lse);
+    else hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, s, S, V, logits, ld, labels, row_loss, row_lse);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, s, rows, S, row_loss, labels, V, loss, count);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
