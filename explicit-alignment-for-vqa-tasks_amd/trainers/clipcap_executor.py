@@ -27,6 +27,27 @@ from .data_parallel import GradSync
 from .optim import ConstantScheduleWithWarmup, CosineAnnealing, FusedAdamW, LinearScheduleWithWarmup
 
 
+def vqa_label_count(input_ids: torch.Tensor, pad_token_id: int, bos_token_id) -> int:
+    """Number of labels the VQA masking rule (clipcap_exector.py:134-150, on the device: ``eavqa_build_labels``) leaves
+    different from -100, counted on the collate's host tensor: per row the tokens after the first <BOS> and before the
+    first pad that are not <BOS> themselves, plus the first pad position (restored to the pad/eos id).  It sizes the
+    scored-row compaction of the lm_head; an over-count would only pad it."""
+    ids = input_ids.detach().cpu()
+    T = ids.shape[1]
+    ar = torch.arange(T)[None]
+    is_pad = ids == pad_token_id
+    first_pad = torch.where(is_pad.any(1), is_pad.float().argmax(1), torch.full((ids.shape[0],), T))
+    before_pad = ar < first_pad[:, None]
+    if bos_token_id is None:
+        answer = torch.zeros_like(before_pad)
+    else:
+        is_bos = (ids == bos_token_id) & before_pad
+        first_bos = torch.where(is_bos.any(1), is_bos.float().argmax(1), torch.full((ids.shape[0],), T))
+        answer = before_pad & (ar > first_bos[:, None]) & (ids != bos_token_id)
+    untouched = (ar > first_pad[:, None]) & ~is_pad
+    return int(answer.sum() + is_pad.any(1).sum() + untouched.sum())
+
+
 class ClipCapExecutor:
     def __init__(self, config, data_loader=None, *, vision_encoder=None, model=None, dtype=torch.bfloat16, device="cuda"):
         self.config = config
@@ -96,6 +117,8 @@ class ClipCapExecutor:
         else:
             bos = getattr(self.tokenizer, "bos_token_id", None)
             labels = ops.build_labels(ids, 0, pad_id, -1 if bos is None else bos, mode=0)   # :134-150
+            if not sample_batched["input_ids"].is_cuda:
+                label_count = vqa_label_count(sample_batched["input_ids"], pad_id, bos)
         prefix = self._clip_embeddings(sample_batched)
         out = self.model(question_tokens=ids, labels=labels, prefix=prefix, question_mask=mask, pad_token_id=pad_id,
                          label_count=label_count)   # :165-171

@@ -165,3 +165,22 @@ def test_fit_from_a_conceptual_captions_parquet_store(tmp_path):
     want, _ = oracle.clipcap_forward(sub(z, "lm."), dict(arch="gpt2", n_layer=NLAY, n_head=NH), mapper, dict(prefix_length=L, mapping_type="mlp"),
                                      b["input_ids"], b["clip_embeddings"], b["attention_mask"], b["labels"])
     assert abs(losses[0].item() - want.item()) <= 2e-4
+
+
+def test_vqa_label_count_matches_the_masking_rule():
+    """The host-side count that sizes the scored-row compaction equals the number of labels the reference rule keeps
+    (oracle.label_mask_vqa), on rows with / without <BOS>, without padding, with repeated <BOS> and an all-pad row."""
+    from eavqa_amd.trainers.clipcap_executor import vqa_label_count
+    pad, bos = 99, 98
+    ids = torch.tensor([[5, 6, bos, 7, 8, pad, pad, pad],
+                        [5, bos, 7, 8, 9, 10, 11, 12],       # no padding: no restored eos
+                        [5, 6, 7, 8, pad, pad, pad, pad],    # no <BOS>: only the restored pad is scored
+                        [bos, 7, bos, 8, 9, pad, pad, pad],  # a second <BOS> is masked itself
+                        [pad, pad, pad, pad, pad, pad, pad, pad],
+                        [5, 6, 7, 8, 9, 10, 11, bos]])
+    want = int((oracle.label_mask_vqa(ids, pad, bos) != -100).sum())
+    assert vqa_label_count(ids, pad, bos) == want
+    g = torch.Generator().manual_seed(0)
+    rnd_ids = torch.randint(90, 100, (64, 12), generator=g)
+    assert vqa_label_count(rnd_ids, pad, bos) == int((oracle.label_mask_vqa(rnd_ids, pad, bos) != -100).sum())
+    assert vqa_label_count(ids, pad, None) == int((oracle.label_mask_vqa(ids, pad, -1) != -100).sum())
