@@ -101,7 +101,7 @@ class Stepper:
 
     def _encode_async(self):
         main = torch.cuda.current_stream()
-        self.side.wait_stream(main)                              # starts behind what is queued on main (AdamW of step i-1)
+        self.side.wait_stream(main)                              # starts behind what is queued on main (backward of step i-1)
         with torch.cuda.stream(self.side):
             emb = self.vit.encode_image(self.batch["pixel_values"])
             ev = torch.cuda.Event()
@@ -118,11 +118,13 @@ class Stepper:
                 self._encode_async()                             # pipeline fill (first step only)
             emb, ready = self.next_emb, self.next_ready
             torch.cuda.current_stream().wait_event(ready)
-        self._apply_update()                                     # AdamW of the previous step
         if self.side is not None:
-            # batch i+1's encode beside the LM FORWARD of batch i (its N = 3840 / 5120 GEMMs leave CUs idle; beside the
-            # backward, whose 128 x 80 tiles fill every CU, the two streams only slow each other down: measured)
+            # batch i+1's encode starts behind the backward of batch i-1: with N > 1 it fills the otherwise exposed wait
+            # for the gradient all-reduce, then runs on beside AdamW and the LM FORWARD of batch i (whose N = 3840 / 5120
+            # GEMMs leave CUs idle; beside the backward, whose 128 x 80 tiles fill every CU, the two streams only slow
+            # each other down: measured)
             self._encode_async()
+        self._apply_update()                                     # all-reduce wait + AdamW of the previous step
         out = self.model(question_tokens=b["input_ids"], prefix=emb, question_mask=b["attention_mask"], labels=b["labels"],
                          pad_token_id=self.pad, question_lengths=b["question_lengths"], label_count=b["label_count"])
         out.loss.backward()
