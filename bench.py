@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-baseline-samples", type=int, default=64, help="0 disables the CPU baseline leg (default: one whole step of the workload, ~10 s)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dp-exchange", choices=["factors", "allreduce"], default="factors",
+                    help="N > 1: all-gather the MLP mapper's gradient factors (default) or all-reduce its flat gradient")
     ap.add_argument("--no-overlap", action="store_true", help="run the CLIP encode on the main stream (no cross-step pipelining)")
     ap.add_argument("--no-fewshot", action="store_true", help="skip the few-shot generate leg (metric M2, reported under 'extra')")
     args = ap.parse_args()
@@ -265,7 +267,11 @@ def main():
     w, vcfg, lcfg, vit, model, opt, batch, pad = build_workload(args.workload, dtype, device, rank)
     torch.cuda.synchronize()
     log("workload built")
-    sync = GradSync(model.clip_project.flat.grad, world)
+    # N > 1: the MLP mapper exchanges gradient FACTORS (all-gather of a few MB) instead of all-reducing 340 MB of gradients
+    factors = world > 1 and args.dp_exchange == "factors" and hasattr(model.clip_project, "dp_factor_exchange")
+    if factors:
+        model.clip_project.dp_factor_exchange = True
+    sync = GradSync(model.clip_project.flat.grad, world, exchange=not factors)
     stepper = Stepper(vit, model, opt, batch, pad, sync, overlap_vit=not args.no_overlap)
 
     def barrier():
@@ -327,6 +333,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}; per-GPU batch {B}, S={S}; fwd+bwd+AdamW; random-init weights",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
+                       **({"dp_exchange": "mapper gradient factors (all-gather)" if factors else "flat gradient all-reduce"} if world > 1 else {}),
                        "algorithmic_gflop_per_sample": round(fps / 1e9, 1),
                        "step_tflops": round(value * fps / 1e12, 1), "final_loss": round(float(loss.item()), 4)},
             "roofline": roof, "cpu_baseline": cpu, "extra": extra,

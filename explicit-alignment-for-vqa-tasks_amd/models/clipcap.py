@@ -124,6 +124,9 @@ class MLP(_MapperBase):
         self._adopt(flat, "", {n: p for n, p in self.model.named_parameters(prefix="model")})
         self.dtype = dtype
         self._w2t = None      # scratch: transposed bf16 copy of the second Linear for its dgrad
+        # data parallel: a process group here switches the weight gradients to the factor exchange (see _MLPFunction)
+        self.dp_group = None
+        self.dp_factor_exchange = False
 
     def forward(self, x: Tensor) -> Tensor:
         """``x``: [..., D] float -> [..., E*L] in the compute dtype (differentiable w.r.t. the parameters)."""
@@ -153,9 +156,18 @@ class _MLPFunction(torch.autograd.Function):
         xT, u, h = ctx.saved_tensors
         dy = dy.contiguous()
         acc = fl.grad_live and not mod.grads_were_reset()
+        # Data parallel, factor exchange: dW = dy^T h is a sum over samples, so instead of all-reducing the 82 M-element dW2
+        # (340 MB for cfg2) every rank all-gathers the per-sample factors - dy [B, E L] and h [B, E L / 2], a few MB - and
+        # computes the weight gradient of the GLOBAL batch itself (K = world x B instead of B).  Same sum, every rank gets
+        # bitwise the same result, no gradient all-reduce is left.
+        gather = None
+        if mod.dp_factor_exchange:
+            from ..trainers.data_parallel import all_gather_rows
+            gather = lambda t: all_gather_rows(t, mod.dp_group)
+        dy_w, h_w = (gather(dy), gather(h)) if gather else (dy, h)
         # layer 2: dW2[N,K] = dy^T h ; db2 = colsum(dy) ; dh = (dy W2) * tanh'(u)
-        _wgrad(dy, h, fl.g("model.2.weight"), acc)
-        ops.colsum(dy, fl.g("model.2.bias"), acc)
+        _wgrad(dy_w, h_w, fl.g("model.2.weight"), acc)
+        ops.colsum(dy_w, fl.g("model.2.bias"), acc)
         # dh = (dy W2) * tanh'(u): W2 is [N=E*L, K=H] (k-contiguous for the forward); its dgrad sums over N, so stream a
         # transposed copy (one HBM pass) through the k-contiguous kernels instead of transposing tile by tile in LDS
         w2 = fl.w("model.2.weight")
@@ -166,8 +178,9 @@ class _MLPFunction(torch.autograd.Function):
             dh = ops.gemm(dy, mod._w2t, act="tanh", aux_in=u)
         else:
             dh = ops.gemm(dy, w2, b_kc=False, act="tanh", aux_in=u)
-        _wgrad(dh, xT, fl.g("model.0.weight"), acc)
-        ops.colsum(dh, fl.g("model.0.bias"), acc)
+        dh_w, x_w = (gather(dh), gather(xT)) if gather else (dh, xT)
+        _wgrad(dh_w, x_w, fl.g("model.0.weight"), acc)
+        ops.colsum(dh_w, fl.g("model.0.bias"), acc)
         fl.grad_live = True
         mod.attach_grads()
         return (None, None) + (None,) * len(mod._names)

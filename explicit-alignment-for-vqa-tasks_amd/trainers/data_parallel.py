@@ -33,15 +33,35 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, local, world
 
 
-class GradSync:
-    """Sum-all-reduce of a flat gradient buffer on a side stream (no-op for a single rank)."""
+def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
+    """[rows, cols] on every rank -> [world * rows, cols] in rank order (identical on every rank).  NCCL/RCCL gathers on
+    the current stream; gloo (CPU tests, single-GPU rehearsals) has no GPU all_gather and is staged through the host."""
+    world = dist.get_world_size(group)
+    t = t.contiguous()
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+        dist.all_gather(parts, t.cpu(), group=group)
+        return torch.cat(parts, 0).to(t.device)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(out, t, group=group)           # one ncclAllGather straight into the result
+    else:
+        dist.all_gather(list(out.chunk(world, 0)), t, group=group)
+    return out
 
-    def __init__(self, flat_grad: torch.Tensor, world: Optional[int] = None, group=None):
+
+class GradSync:
+    """Sum-all-reduce of a flat gradient buffer on a side stream (no-op for a single rank).  ``exchange=False``: the
+    gradients in the buffer are already summed over the ranks (the MLP mapper's factor exchange, models/clipcap.py), only
+    ``grad_scale`` is still needed."""
+
+    def __init__(self, flat_grad: torch.Tensor, world: Optional[int] = None, group=None, exchange: bool = True):
         self.buf = flat_grad
         self.group = group
+        self.exchange = exchange
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.on_gpu = flat_grad.is_cuda
-        self.stream = torch.cuda.Stream() if (self.on_gpu and self.world > 1) else None
+        self.stream = torch.cuda.Stream() if (self.on_gpu and self.world > 1 and exchange) else None
         self._pending = None
 
     @property
@@ -51,7 +71,7 @@ class GradSync:
 
     def start(self) -> None:
         """Enqueue the all-reduce after everything already queued on the current stream."""
-        if self.world == 1:
+        if self.world == 1 or not self.exchange:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())

@@ -53,7 +53,21 @@ def _worker(rank, world, port, results):
     gathered = [torch.zeros_like(mean_grad) for _ in range(world)]
     dist.all_gather(gathered, mean_grad)
     same = all(torch.equal(gathered[0], t) for t in gathered)
-    results[rank] = (bool(ok), bool(ok2), bool(same))
+    # factor exchange (models/clipcap.py _MLPFunction.backward): all-gathering the per-sample factors and forming the
+    # weight gradient of the global batch equals the all-reduced sum of the per-rank weight gradients
+    from eavqa_amd.trainers.data_parallel import all_gather_rows
+    gg = torch.Generator().manual_seed(7 + rank)
+    dy, h = torch.randn(B, O, generator=gg), torch.randn(B, H, generator=gg)
+    dy_all, h_all = all_gather_rows(dy), all_gather_rows(h)
+    assert dy_all.shape == (world * B, O) and torch.equal(dy_all[rank * B:(rank + 1) * B], dy)
+    local = dy.T @ h
+    dist.all_reduce(local)
+    ok3 = torch.allclose(dy_all.T @ h_all, local, atol=1e-5)
+    nosync = GradSync(buf, world, exchange=False)
+    before = buf.clone()
+    nosync.start(); nosync.finish()
+    ok3 = ok3 and torch.equal(buf, before) and nosync.grad_scale == 1.0 / world
+    results[rank] = (bool(ok), bool(ok2), bool(same and ok3))
     dist.destroy_process_group()
 
 
