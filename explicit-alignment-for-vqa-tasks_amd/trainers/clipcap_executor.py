@@ -168,7 +168,14 @@ class ClipCapExecutor:
         if self.optimizer is None:
             self.configure_optimizers()
         if self.grad_sync is None:
-            self.grad_sync = GradSync(self.model.clip_project.flat.grad)
+            import torch.distributed as dist
+            mapper = self.model.clip_project
+            # N > 1 with the MLP mapper: all-gather the gradient factors instead of all-reducing the flat gradient
+            # (data_parallel.py / models/clipcap.py); the transformer mapper keeps the all-reduce
+            factors = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and hasattr(mapper, "dp_factor_exchange")
+            if factors:
+                mapper.dp_factor_exchange = True
+            self.grad_sync = GradSync(mapper.flat.grad, exchange=not factors)
         self.model.train()
         losses = []
         for batch_idx, batch in enumerate(batches):
