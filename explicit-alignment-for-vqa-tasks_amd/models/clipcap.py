@@ -196,8 +196,13 @@ def _to_compute(x: Tensor, T: torch.dtype) -> Tensor:
 
 
 def _wgrad(dy: Tensor, x: Tensor, gview: Tensor, accumulate: bool) -> None:
-    """gview[N,K] (+)= dy[M,N]^T @ x[M,K]  - both operands transposed in memory (m contiguous dim is not k)."""
-    ops.gemm(dy, x, a_kc=False, b_kc=False, out=gview, residual=gview if accumulate else None)
+    """gview[N,K] (+)= dy[M,N]^T @ x[M,K]  - both operands transposed in memory (m contiguous dim is not k).  In bf16 the
+    two (small) factors are transposed first so that the product runs on the k-contiguous LDS-DMA kernels: 162 vs 621 us for
+    the MLP mapper's dW2 at M = 512 (eight ranks' gathered factors), 88 vs 115 us at M = 64."""
+    if dy.dtype == torch.bfloat16 and dy.shape[0] % 32 == 0 and dy.is_contiguous() and x.is_contiguous():
+        ops.gemm(ops.transpose(dy), ops.transpose(x), out=gview, residual=gview if accumulate else None)
+    else:
+        ops.gemm(dy, x, a_kc=False, b_kc=False, out=gview, residual=gview if accumulate else None)
 
 
 class TransformerMapper(_MapperBase):
