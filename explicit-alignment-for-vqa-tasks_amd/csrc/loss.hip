@@ -112,7 +112,7 @@ __global__ __launch_bounds__(1024) void ce_reduce_kernel(int rows, int S, const 
     sl[threadIdx.x] = a; sc[threadIdx.x] = c;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+        if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) { count[0] = sc[0]; loss[0] = sl[0] / sc[0]; }
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(GP_THREADS) void greedy_pick_kernel(int V, const fl
     sv[threadIdx.x] = best; si[threadIdx.x] = idx;
     __syncthreads();
     for (int o = GP_THREADS / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o) {
+        if ((int)threadIdx.x < o) {
             const float v2 = sv[threadIdx.x + o];
             const int i2 = si[threadIdx.x + o];
             if (v2 > sv[threadIdx.x] || (v2 == sv[threadIdx.x] && i2 < si[threadIdx.x])) { sv[threadIdx.x] = v2; si[threadIdx.x] = i2; }
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(GP_THREADS) void greedy_pick_kernel(int V, const fl
         sv[threadIdx.x] = sum;
         __syncthreads();
         for (int o = GP_THREADS / 2; o > 0; o >>= 1) {
-            if (threadIdx.x < o) sv[threadIdx.x] += sv[threadIdx.x + o];
+            if ((int)threadIdx.x < o) sv[threadIdx.x] += sv[threadIdx.x + o];
             __syncthreads();
         }
         if (threadIdx.x == 0) logprob[b] = -logf(sv[0]);
