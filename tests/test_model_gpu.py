@@ -391,3 +391,36 @@ def test_full_size_cfg2_properties_bf16():
     gen = dict(question_tokens=b["input_ids"][:4, :8], prefix=b["clip_embeddings"][:4], question_mask=b["attention_mask"][:4, :8],
                max_length=1, pad_token_id=cfg.eos_token_id, eos_token_id=None)
     assert model.generate(use_cache=True, **gen) == model.generate(use_cache=False, **gen)
+
+
+@pytest.mark.parametrize("arch,B", [("gpt2", 5), ("opt", 33), ("opt", 64)])
+def test_decode_fast_path_logits_match_full_forward_bf16(arch, B):
+    """The bf16 decode step (C driver: split-K GEMMs + fused finish / LayerNorm + decode attention over the KV cache) against
+    the logits of a full re-forward over the grown sequence - the reference's own algorithm (clipcap.py:414-419) - for three
+    consecutive steps, with ragged prompt masks.  Same bf16 operands, different summation orders."""
+    from eavqa_amd import ops
+    from eavqa_amd.models import decode as dec
+    from eavqa_amd.models.lm import FrozenCausalLM, LMConfig, random_init_state_dict
+    E, H, F, NL, V, NPOS = 256, 4, 1024, 2, 512, 64
+    cfg = (LMConfig("gpt2", NL, H, E, F, V, NPOS, 1e-5, "gelu_new", V - 1, None) if arch == "gpt2"
+           else LMConfig("opt", NL, H, E, F, V, NPOS, 1e-5, "relu", 2, 1))
+    lm = FrozenCausalLM(cfg, random_init_state_dict(cfg, 5, DEV), torch.bfloat16, DEV)
+    g = torch.Generator().manual_seed(B)
+    S0, steps = 9, 3
+    S_max = S0 + steps
+    tok = torch.randint(3, V - 1, (B, S_max), generator=g)
+    lens = torch.randint(4, S0 + 1, (B,), generator=g); lens[0] = S0
+    qm = torch.ones(B, S_max, dtype=torch.long)
+    qm[:, :S0] = (torch.arange(S0)[None] < lens[:, None]).long()          # right-padded prompt, generated positions attended
+    src, mask, pos = ops.build_prefix_rows(tok.to(DEV), qm.to(DEV), 0, cfg.pos_mode)
+    cache = dec._KVCache(lm, B, S_max, B * S0)
+    logits = dec._prefill(lm, cache, None, src[:, :S0].contiguous(), pos[:, :S0].contiguous(), mask, B, S0, S_max)
+    for t in range(steps + 1):
+        S = S0 + t
+        full = lm.forward(None, src[:, :S].contiguous(), pos[:, :S].contiguous(), mask[:, :S].contiguous(), B, S, logits="last")["logits"]
+        a, b = logits[:, :V].float().cpu(), full[:, :V].float().cpu()
+        assert (a - b).abs().max().item() <= 4e-2 * max(1.0, b.abs().max().item()), (t, (a - b).abs().max().item())
+        if t == steps:
+            break
+        raw = src[:, S].contiguous()                                       # teacher-forced next token
+        logits = dec._decode_step(lm, cache, raw, pos[:, S].contiguous(), mask, B, S, S_max)
