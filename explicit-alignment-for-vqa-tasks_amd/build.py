@@ -1,12 +1,15 @@
 """Build libeavqa_hip.so (gfx950) in-tree with hipcc.
 
 ``python -m eavqa_amd.build`` or ``__graft_entry__.build()``.  hipcc cross-compiles without a
-GPU.  Objects are cached under ``csrc/_obj`` keyed by source mtime so a rebuild after a one-file
-edit takes seconds.  The resulting ``.so`` lives next to the sources (git-ignored, but it travels
+GPU.  Objects are cached under ``csrc/_obj`` keyed by a content hash of the source, every in-repo
+file it includes (from hipcc -MD) and the flags, so a rebuild after a one-file edit takes seconds
+and an edit to an included file is never missed.  The resulting ``.so`` lives next to the sources (git-ignored, but it travels
 to the GPU box with the repo snapshot).
 """
 from __future__ import annotations
 
+import hashlib
+import json
 import os
 import shutil
 import subprocess
@@ -39,22 +42,53 @@ def _newer(dst: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
+FLAGS = ["-O3", "-std=c++17", "-fPIC"]
+
+
+def _digest(rel_paths, extra: str) -> str:
+    """Content hash of the given files (paths relative to the repo root, in order) plus ``extra`` (the compile flags)."""
+    h = hashlib.sha256(extra.encode())
+    for p in rel_paths:
+        h.update(p.encode())
+        with open(os.path.join(ROOT, p), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _read_deps(dfile: str):
+    """In-repo prerequisites of a ``-MD`` make fragment, relative to the repo root (system headers are skipped), so the
+    cache key stays valid when the tree is copied elsewhere (the GPU box)."""
+    with open(dfile) as f:
+        text = f.read().replace("\\\n", " ")
+    deps = [os.path.abspath(t) for t in text.split(":", 1)[1].split()]
+    return sorted({os.path.relpath(d, ROOT) for d in deps if d.startswith(ROOT + os.sep)})
+
+
 def _compile(src: str, verbose: bool) -> str:
-    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    """One object, cached by CONTENT: the key hashes the flags, the source and every in-repo file the previous compile
+    reported as included (hipcc -MD), so an edit to e.g. attention_mfma.hip (included by attention.hip) rebuilds
+    attention.o even though attention.hip itself is untouched."""
+    stem = os.path.splitext(src)[0]
+    obj, dfile, kfile = (os.path.join(OBJ, stem + ext) for ext in (".o", ".d", ".key.json"))
     path = os.path.join(CSRC, src)
-    deps = [path, os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "eavqa.h")]
-    if _newer(obj, deps):
-        return obj
-    cmd = [_hipcc(), "-O3", "-std=c++17", "-fPIC", f"-I{INCLUDE}", f"-I{CSRC}", "-c", path, "-o", obj]
-    if src.endswith(".hip"):
-        cmd.insert(1, f"--offload-arch={ARCH}")
-    else:
-        cmd[1:1] = ["-x", "hip", f"--offload-arch={ARCH}"]
+    flags = FLAGS + [f"--offload-arch={ARCH}"] + ([] if src.endswith(".hip") else ["-x", "hip"])
+    cmd = [_hipcc()] + flags + [f"-I{INCLUDE}", f"-I{CSRC}", "-MD", "-MF", dfile, "-c", path, "-o", obj]
+    if os.path.exists(obj) and os.path.exists(kfile):
+        try:
+            with open(kfile) as f:
+                key = json.load(f)
+            if key["digest"] == _digest(key["deps"], " ".join(flags)):
+                return obj
+        except (OSError, KeyError, ValueError):
+            pass
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    deps = _read_deps(dfile)
+    with open(kfile, "w") as f:
+        json.dump({"deps": deps, "digest": _digest(deps, " ".join(flags))}, f)
     return obj
 
 
