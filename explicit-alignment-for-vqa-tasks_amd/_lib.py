@@ -24,9 +24,6 @@ SIGNATURES = {
     "eavqa_strerror": [i32],
     "eavqa_check_device": [],
     "eavqa_gemm": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i32, f32, ptr, i32, ptr, ptr, i64, ptr, i64, ptr],
-    "eavqa_debug_disable_fast_gemm": [i32],
-    "eavqa_debug_gemm_stagger": [i32],
-    "eavqa_debug_attention_valu": [i32],
     "eavqa_layernorm_fwd": [i32, i32, i32, i32, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, ptr, ptr],
     "eavqa_layernorm_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, ptr],
     "eavqa_attention_fwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i64, ptr, i32, f32, ptr, ptr],
@@ -50,6 +47,7 @@ SIGNATURES = {
     "eavqa_embed_assemble_bwd": [i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr],
     "eavqa_build_labels": [i32, i32, i32, i32, ptr, i64, i64, ptr, ptr],
     "eavqa_ce_fwd": [i32, i32, i32, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr],
+    "eavqa_guard_count": [ptr, i32, ptr, ptr],
     "eavqa_ce_bwd": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr],
     "eavqa_greedy_pick": [i32, i32, ptr, i64, i64, i64, ptr, ptr, i64, ptr, ptr, ptr],
     "eavqa_adamw": [i64, ptr, ptr, ptr, ptr, i32, f32, f32, f32, f32, f32, f32, i32, ptr, ptr],
@@ -66,7 +64,12 @@ class LMLayer(C.Structure):
 SIGNATURES["eavqa_lm_block_workspace_bytes"] = [i32, i32, i32, i32]
 SIGNATURES["eavqa_lm_block_forward"] = [i32, i32, C.POINTER(LMLayer), i32, i32, i32, i32, f32, i32, i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr]
 
-_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_debug_disable_fast_gemm": None, "eavqa_debug_gemm_stagger": None, "eavqa_debug_attention_valu": None, "eavqa_lm_block_workspace_bytes": C.c_int64}
+# include/eavqa_test.h: the same entry points with an explicit kernel selector (tests and tools only)
+SIGNATURES["eavqa_gemm_ex"] = SIGNATURES["eavqa_gemm"] + [i32]
+SIGNATURES["eavqa_attention_fwd_ex"] = SIGNATURES["eavqa_attention_fwd"] + [i32]
+SIGNATURES["eavqa_attention_bwd_ex"] = SIGNATURES["eavqa_attention_bwd"] + [i32]
+
+_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_lm_block_workspace_bytes": C.c_int64}
 
 _lib = None
 

@@ -15,8 +15,6 @@
 
 namespace {
 
-bool g_force_valu = false;   // test hook: keep bf16 on the vector-ALU kernels
-bool g_split_bwd = false;    // test hook: two-kernel backward even when the problem is one tile
 
 constexpr int CK = 8;  // keys per softmax chunk
 
@@ -547,12 +545,13 @@ bool decode_supported(int dtype, int Sq, int Sk, int hd, const int32_t* cu, int6
 
 }  // namespace
 
-extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,
+extern "C" int eavqa_attention_fwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
                                    const void* q, int64_t ldq, const void* k, int64_t ldk,
                                    const void* v, int64_t ldv, void* o, int64_t ldo,
                                    int64_t q_batch_rows, int64_t kv_batch_rows,
                                    const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal,
-                                   float scale, float* lse, void* stream) {
+                                   float scale, float* lse, void* stream, int path) {
+    const bool g_force_valu = (path & 1) != 0;      // include/eavqa_test.h: bf16 on the vector-ALU kernels
     if (!q || !k || !v || !o) return EAVQA_E_ARG;
     int rc = check_common(dtype, B, H, Sq, Sk, hd);
     if (rc) return rc;
@@ -598,15 +597,25 @@ extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int 
     return dtype == EAVQA_F32 ? dispatch<float>(K_FWD, p, s) : dispatch<bf16_t>(K_FWD, p, s);
 }
 
-extern "C" void eavqa_debug_attention_valu(int force) { g_force_valu = (force & 1) != 0; g_split_bwd = (force & 2) != 0; }
+extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,
+                                   const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                   const void* v, int64_t ldv, void* o, int64_t ldo,
+                                   int64_t q_batch_rows, int64_t kv_batch_rows,
+                                   const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal,
+                                   float scale, float* lse, void* stream) {
+    return eavqa_attention_fwd_ex(dtype, B, H, Sq, Sk, hd, q, ldq, k, ldk, v, ldv, o, ldo, q_batch_rows, kv_batch_rows, key_mask,
+                                  ld_mask, cu_seqlens, causal, scale, lse, stream, 0);
+}
 
-extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int hd,
+extern "C" int eavqa_attention_bwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
                                    const void* q, int64_t ldq, const void* k, int64_t ldk,
                                    const void* v, int64_t ldv, const void* o, int64_t ldo,
                                    const void* d_o, int64_t lddo,
                                    void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
                                    const int32_t* key_mask, const int32_t* cu_seqlens, int causal, float scale,
-                                   const float* lse, float* delta, void* stream) {
+                                   const float* lse, float* delta, void* stream, int path) {
+    const bool g_force_valu = (path & 1) != 0;      // bf16 on the vector-ALU kernels
+    const bool g_split_bwd = (path & 2) != 0;       // two-kernel backward even when the problem is one tile
     if (!q || !k || !v || !o || !d_o || !dq || !dk || !dv || !lse || !delta) return EAVQA_E_ARG;
     int rc = check_common(dtype, B, H, Sq, Sk, hd);
     if (rc) return rc;
@@ -634,4 +643,15 @@ extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int 
     rc = dtype == EAVQA_F32 ? dispatch<float>(K_DQ, p, s) : dispatch<bf16_t>(K_DQ, p, s);
     if (rc) return rc;
     return dtype == EAVQA_F32 ? dispatch<float>(K_DKV, p, s) : dispatch<bf16_t>(K_DKV, p, s);
+}
+
+extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int hd,
+                                   const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                   const void* v, int64_t ldv, const void* o, int64_t ldo,
+                                   const void* d_o, int64_t lddo,
+                                   void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                                   const int32_t* key_mask, const int32_t* cu_seqlens, int causal, float scale,
+                                   const float* lse, float* delta, void* stream) {
+    return eavqa_attention_bwd_ex(dtype, B, H, Sq, Sk, hd, q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, dq, lddq, dk, lddk, dv, lddv,
+                                  key_mask, cu_seqlens, causal, scale, lse, delta, stream, 0);
 }

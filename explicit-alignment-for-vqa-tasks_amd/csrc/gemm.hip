@@ -19,10 +19,17 @@
 
 namespace {
 
-bool g_disable_fast = false;   // test hook: exercise the general kernel on fast-path shapes
-int g_stagger = 0;             // experiment knob: s_sleep units for odd co-resident blocks of the fast kernel
-int g_ablate = 0;              // experiment knob: ablation variant of the fast kernel (timing only)
-int g_deep = 0;                // 2 = force the 8-stage ring (experiment)
+// Kernel-selection knobs of eavqa_gemm_ex (include/eavqa_test.h), decoded per call: the library keeps no mutable state.
+struct Knobs {
+    int stagger;        // [7:0]   s_sleep units for odd co-resident blocks of the fast kernel (experiment)
+    int ablate;         // [10:8]  timing-only ablation variant of the fast kernel (results wrong when non-zero)
+    int big_mode;       // [17:16] 0 = 256 x 256 kernel by shape, 1 never, 2 always (K % 64 == 0)
+    int deep;           // [21:20] 2 = force the 8-stage ring (experiment)
+    int shape_mode;     // [26:24] 0 = shaped tiles by cost model, 1 never, 2.. force SHAPES[id - 2]
+    bool disable_fast;  // [28]    general register-staged kernel on fast-path shapes (parity coverage of that kernel)
+    explicit Knobs(int k = 0) : stagger(k & 0xff), ablate((k >> 8) & 7), big_mode((k >> 16) & 3), deep((k >> 20) & 3),
+                                shape_mode((k >> 24) & 7), disable_fast(((k >> 28) & 1) != 0) {}
+};
 
 struct GemmParams {
     const void* A; const void* B; void* C;
@@ -487,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
 
 typedef void (*fast_kernel_t)(GemmParams, int, int, int);
 
-int launch_fast(const GemmParams& p, hipStream_t stream) {
+int launch_fast(const GemmParams& p, hipStream_t stream, const Knobs& kn) {
     static const fast_kernel_t kernels[8] = {gemm_bf16_fast_kernel<0, 4>, gemm_bf16_fast_kernel<1, 4>, gemm_bf16_fast_kernel<2, 4>,
                                              gemm_bf16_fast_kernel<3, 4>, gemm_bf16_fast_kernel<4, 4>,
                                              gemm_bf16_fast_kernel<0, 8>, gemm_bf16_fast_kernel<4, 8>, gemm_bf16_fast_kernel<5, 4>};
@@ -501,8 +508,8 @@ int launch_fast(const GemmParams& p, hipStream_t stream) {
     }
     // deep ring (8 stages, one workgroup per CU): measured on MI355X to give no gain over 4 stages even for grids of one
     // tile per CU (the LDS-DMA rate of a CU is a throughput cap, not a bytes-in-flight limit) - kept as an experiment knob
-    const bool deep = g_deep == 2;
-    const fast_kernel_t kernel = deep ? (g_ablate == 4 ? kernels[6] : kernels[5]) : kernels[g_ablate <= 4 ? g_ablate : (g_ablate == 5 ? 7 : 0)];
+    const bool deep = kn.deep == 2;
+    const fast_kernel_t kernel = deep ? (kn.ablate == 4 ? kernels[6] : kernels[5]) : kernels[kn.ablate <= 4 ? kn.ablate : (kn.ablate == 5 ? 7 : 0)];
     const int lds_bytes = deep ? 8 * FSTAGE : CS_BYTES;
     // XCD grid gx x gy = 8 minimising the panels one XCD touches (rows + cols of its rectangle)
     int best_gx = 8, best_cost = 1 << 30;
@@ -514,7 +521,7 @@ int launch_fast(const GemmParams& p, hipStream_t stream) {
     }
     const int gx = best_gx, gy = 8 / gx;
     const int per_xcd = ((p.tiles_m + gx - 1) / gx) * ((p.tiles_n + gy - 1) / gy);
-    hipLaunchKernelGGL(kernel, dim3(per_xcd * 8), dim3(256), lds_bytes, stream, p, gx, gy, g_stagger);
+    hipLaunchKernelGGL(kernel, dim3(per_xcd * 8), dim3(256), lds_bytes, stream, p, gx, gy, kn.stagger);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }
@@ -733,8 +740,6 @@ int launch_shaped(const GemmParams& p, hipStream_t stream) {
     return EAVQA_OK;
 }
 
-// test / experiment knob: 0 = choose by shape, 1 = never a shaped tile, else force SHAPES[id - 2]
-int g_shape_mode = 0;
 
 // `rate`: measured ns per 64-byte operand row and K-step (32) of one workgroup alone on a CU (K = 5120 probes and the
 // cfg2 shapes, tools/gemm_bench.py): the wider 8-wave tiles get closer to the MFMA / LDS limits and pay more per byte.
@@ -894,13 +899,10 @@ int launch_big(const GemmParams& p, hipStream_t stream) {
     return EAVQA_OK;
 }
 
-// 0 = choose by shape, 1 = never the big kernel, 2 = always (when K % 64 == 0)
-int g_big_mode = 0;
-
-bool use_big(const GemmParams& p) {
+bool use_big(const GemmParams& p, const Knobs& kn) {
     if (p.K % GBK) return false;
-    if (g_big_mode == 1) return false;
-    if (g_big_mode == 2) return true;
+    if (kn.big_mode == 1) return false;
+    if (kn.big_mode == 2) return true;
     const int tiles = ((p.M + GBM - 1) / GBM) * ((p.N + GBN - 1) / GBN);
     return tiles >= 144;     // measured crossover on MI355X: below ~140 tiles the 128 x 128 kernel (more CUs busy) wins
 }
@@ -1132,18 +1134,13 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" void eavqa_debug_disable_fast_gemm(int disable) { g_disable_fast = disable != 0; }
-extern "C" void eavqa_debug_gemm_stagger(int units) {
-    g_stagger = units & 0xff; g_ablate = (units >> 8) & 7; g_big_mode = (units >> 16) & 3; g_deep = (units >> 20) & 3;
-    g_shape_mode = (units >> 24) & 7;
-}
-
-extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
-                          const void* A, int64_t lda, const void* B, int64_t ldb,
-                          void* C, int64_t ldc, int out_f32, float alpha,
-                          const float* bias, int act,
-                          const void* aux_in, void* aux_out, int64_t ld_aux,
-                          const float* residual, int64_t ldr, void* stream) {
+extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
+                             const void* A, int64_t lda, const void* B, int64_t ldb,
+                             void* C, int64_t ldc, int out_f32, float alpha,
+                             const float* bias, int act,
+                             const void* aux_in, void* aux_out, int64_t ld_aux,
+                             const float* residual, int64_t ldr, void* stream, int knobs) {
+    const Knobs kn(knobs);
     if (!A || !B || !C) return EAVQA_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0) return EAVQA_E_ARG;
     if (dtype != EAVQA_F32 && dtype != EAVQA_BF16) return EAVQA_E_DTYPE;
@@ -1174,23 +1171,23 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
     p.vec_bias = (reinterpret_cast<uintptr_t>(bias) % 16) == 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
-        if (a_kc && b_kc && !g_disable_fast && M <= 64 && (K % 32) == 0 && N >= 64) return launch_skinny(p, s);
-        if (a_kc && b_kc && !g_disable_fast && (K % FBK) == 0) {
-            if (g_shape_mode >= 2 && g_shape_mode < 7) return SHAPES[g_shape_mode - 2].launch(p, s);
-            const bool big_ok = (K % GBK) == 0 && g_big_mode != 1;
-            if (big_ok && g_big_mode == 2) return launch_big(p, s);
+        if (a_kc && b_kc && !kn.disable_fast && M <= 64 && (K % 32) == 0 && N >= 64) return launch_skinny(p, s);
+        if (a_kc && b_kc && !kn.disable_fast && (K % FBK) == 0) {
+            if (kn.shape_mode >= 2 && kn.shape_mode < 7) return SHAPES[kn.shape_mode - 2].launch(p, s);
+            const bool big_ok = (K % GBK) == 0 && kn.big_mode != 1;
+            if (big_ok && kn.big_mode == 2) return launch_big(p, s);
             // candidates in order of preference at equal cost: 128 x 128 (two workgroups per CU), 256 x 256, shaped tiles
             float best = tile_cost(p, 128, 128, RATE_FAST);
             int pick = -1;                                   // -1 fast, -2 big, >= 0 SHAPES[pick]
-            if (big_ok && use_big(p)) { best = fminf(best, tile_cost(p, 256, 256, RATE_BIG)); pick = -2; }
-            if (g_shape_mode != 1)
+            if (big_ok && use_big(p, kn)) { best = fminf(best, tile_cost(p, 256, 256, RATE_BIG)); pick = -2; }
+            if (kn.shape_mode != 1)
                 for (int i = 0; i < 5; ++i) {
                     const float c = tile_cost(p, SHAPES[i].bm, SHAPES[i].bn, SHAPES[i].rate);
                     if (c < best * 0.95f) { best = c; pick = i; }
                 }
             if (pick >= 0) return SHAPES[pick].launch(p, s);
             if (pick == -2) return launch_big(p, s);
-            return launch_fast(p, s);
+            return launch_fast(p, s, kn);
         }
         if (a_kc && b_kc) return launch(gemm_bf16_kernel<true, true>, p, s);
         if (a_kc && !b_kc) return launch(gemm_bf16_kernel<true, false>, p, s);
@@ -1201,4 +1198,14 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
     if (a_kc && !b_kc) return launch(gemm_f32_kernel<true, false>, p, s);
     if (!a_kc && b_kc) return launch(gemm_f32_kernel<false, true>, p, s);
     return launch(gemm_f32_kernel<false, false>, p, s);
+}
+
+extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
+                          const void* A, int64_t lda, const void* B, int64_t ldb,
+                          void* C, int64_t ldc, int out_f32, float alpha,
+                          const float* bias, int act,
+                          const void* aux_in, void* aux_out, int64_t ld_aux,
+                          const float* residual, int64_t ldr, void* stream) {
+    return eavqa_gemm_ex(dtype, a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, out_f32, alpha, bias, act, aux_in, aux_out, ld_aux,
+                         residual, ldr, stream, 0);
 }

@@ -105,17 +105,25 @@ __global__ __launch_bounds__(1024) void ce_reduce_kernel(int rows, int S, const 
                                                          int V, float* loss, float* count) {
     __shared__ float sl[1024], sc[1024];
     float a = 0.f, c = 0.f;
+    int bad = 0;                       // a label that is neither ignore_index nor a class: torch.cross_entropy asserts on the device
     for (int r = threadIdx.x; r < rows; r += 1024) {
         const int64_t lab = shifted_label(labels, S, r);
         if (lab >= 0 && lab < V) { a += row_loss[r]; c += 1.f; }
+        else if (lab != -100) bad = 1;
     }
+    bad = __syncthreads_or(bad);
     sl[threadIdx.x] = a; sc[threadIdx.x] = c;
     __syncthreads();
     for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { count[0] = sc[0]; loss[0] = sl[0] / sc[0]; }
+    // an out-of-range label (e.g. a tokenizer longer than the embedding matrix) poisons the loss instead of being skipped
+    if (threadIdx.x == 0) { count[0] = sc[0]; loss[0] = bad ? __builtin_nanf("") : sl[0] / sc[0]; }
+}
+
+__global__ void guard_count_kernel(const int32_t* count, int capacity, float* loss) {
+    if (count[0] > capacity) loss[0] = __builtin_nanf("");
 }
 
 template <typename T>
@@ -207,6 +215,13 @@ extern "C" int eavqa_ce_fwd(int B, int S, int V, const float* logits, int64_t ld
     if (V <= CE_T * CE_NPT) hipLaunchKernelGGL(ce_fwd_row_kernel, dim3(rows), dim3(CE_T), 0, s, S, V, logits, ld, labels, row_loss, row_lse);
     else hipLaunchKernelGGL(ce_fwd_kernel, dim3(rows), dim3(256), 0, s, S, V, logits, ld, labels, row_loss, row_lse);
     hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, s, rows, S, row_loss, labels, V, loss, count);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_guard_count(const int32_t* count, int capacity, float* loss, void* stream) {
+    if (!count || !loss || capacity < 0) return EAVQA_E_ARG;
+    hipLaunchKernelGGL(guard_count_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), count, capacity, loss);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }

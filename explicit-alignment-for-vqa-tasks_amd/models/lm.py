@@ -318,9 +318,9 @@ class FrozenCausalLM:
             hf = ops.layernorm_fwd(x, self.lnf_g, self.lnf_b, c.eps, T)
         out["hidden"] = hf
         if labels is not None or logits == "all":
-            sel = None
+            sel = sel_count = None
             if pack and labels is not None and n_scored is not None and logits != "all" and 0 < n_scored < M:
-                sel, ce_labels, _ = ops.select_rows(row_labels, int(n_scored))
+                sel, ce_labels, sel_count = ops.select_rows(row_labels, int(n_scored))
                 lg = self._head(ops.gather_rows(hf, sel))
             else:
                 lg = self._head(hf)
@@ -328,6 +328,10 @@ class FrozenCausalLM:
             out["logits"], out["sel"] = lg, sel
             if labels is not None:
                 loss, count, row_lse = ops.ce_fwd(lg, ce_labels, self.vocab)
+                if sel_count is not None:
+                    # the host-side label count sized the compaction: more labelled rows than that would have been dropped
+                    # silently, so the loss turns NaN instead (on the device, no synchronisation)
+                    ops.guard_count(sel_count, int(n_scored), loss)
                 out["loss"], out["count"] = loss, count
                 if save:
                     out["tape"] = dict(layers=tape, x_last=x, meanf=meanf, rstdf=rstdf, logits=lg, labels=ce_labels, sel=sel,

@@ -29,6 +29,14 @@ def _stream() -> int:
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
+class KernelSelect:
+    """Kernel selectors handed to the ``*_ex`` entry points of include/eavqa_test.h.  Both are 0 in the product path (the
+    library chooses by shape); the parity tests and tools/gemm_bench.py set them to cover / time a particular kernel.  The
+    state lives HERE, in the test-facing Python layer - libeavqa_hip.so itself holds no mutable state."""
+    gemm = 0
+    attention = 0
+
+
 def _p(t: Optional[Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -65,9 +73,13 @@ def gemm(a: Tensor, b: Tensor, *, a_kc: bool = True, b_kc: bool = True, bias: Op
         raise _lib.EavqaError("gemm out dtype must be float32 or the operand dtype")
     out_f32 = out.dtype == torch.float32
     aux = aux_in if aux_in is not None else aux_out
-    call("eavqa_gemm", dt, int(a_kc), int(b_kc), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out),
-         int(out_f32), float(alpha), _p(bias), ACT[act], _p(aux_in), _p(aux_out), _ld(aux) if aux is not None else 0,
-         _p(residual), _ld(residual) if residual is not None else 0, _stream())
+    args = (dt, int(a_kc), int(b_kc), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out),
+            int(out_f32), float(alpha), _p(bias), ACT[act], _p(aux_in), _p(aux_out), _ld(aux) if aux is not None else 0,
+            _p(residual), _ld(residual) if residual is not None else 0, _stream())
+    if KernelSelect.gemm:
+        call("eavqa_gemm_ex", *args, KernelSelect.gemm)
+    else:
+        call("eavqa_gemm", *args)
     return out
 
 
@@ -110,8 +122,12 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, H: int, Sq: int, Sk: 
     _dev(q)
     o = out if out is not None else torch.empty((q.shape[0] if cu_seqlens is not None else B * Sq, H * hd), device=q.device, dtype=q.dtype)
     lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32) if save_lse else None
-    call("eavqa_attention_fwd", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o),
-         q_batch_rows, kv_batch_rows, _p(key_mask), ld_mask, _p(cu_seqlens), int(causal), float(scale), _p(lse), _stream())
+    args = (dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o),
+            q_batch_rows, kv_batch_rows, _p(key_mask), ld_mask, _p(cu_seqlens), int(causal), float(scale), _p(lse), _stream())
+    if KernelSelect.attention:
+        call("eavqa_attention_fwd_ex", *args, KernelSelect.attention)
+    else:
+        call("eavqa_attention_fwd", *args)
     return (o, lse) if save_lse else o
 
 
@@ -124,9 +140,13 @@ def attention_bwd(q, k, v, o, d_o, lse, B, H, Sq, Sk, hd, *, key_mask=None, caus
     dk = dk if dk is not None else torch.empty((nk, H * hd), device=q.device, dtype=q.dtype)
     dv = dv if dv is not None else torch.empty((nk, H * hd), device=q.device, dtype=q.dtype)
     delta = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
-    call("eavqa_attention_bwd", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o),
-         _p(d_o), _ld(d_o), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(key_mask), _p(cu_seqlens), int(causal),
-         float(scale), _p(lse), _p(delta), _stream())
+    args = (dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o),
+            _p(d_o), _ld(d_o), _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(key_mask), _p(cu_seqlens), int(causal),
+            float(scale), _p(lse), _p(delta), _stream())
+    if KernelSelect.attention:
+        call("eavqa_attention_bwd_ex", *args, KernelSelect.attention)
+    else:
+        call("eavqa_attention_bwd", *args)
     return dq, dk, dv
 
 
@@ -221,6 +241,11 @@ def ce_fwd(logits: Tensor, labels: Tensor, V: int):
     count = torch.empty(1, device=logits.device, dtype=torch.float32)
     call("eavqa_ce_fwd", B, S, V, _p(logits), _ld(logits), _p(labels), _p(row_loss), _p(row_lse), _p(loss), _p(count), _stream())
     return loss, count, row_lse
+
+
+def guard_count(count: Tensor, capacity: int, loss: Tensor) -> None:
+    """``loss[0] = NaN`` on the device when ``count[0] > capacity`` (an under-sized scored-row compaction)."""
+    call("eavqa_guard_count", _p(count), int(capacity), _p(loss), _stream())
 
 
 def ce_bwd(logits: Tensor, labels: Tensor, V: int, row_lse: Tensor, count: Tensor, gscale: Tensor, dtype: torch.dtype,

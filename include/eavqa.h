@@ -78,16 +78,6 @@ int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                const void* aux_in, void* aux_out, int64_t ld_aux,
                const float* residual, int64_t ldr, void* stream);
 
-/* Test hook (host, not thread-safe): non-zero routes bf16 k-contiguous GEMMs with K % 32 == 0 through the
- * general register-staged kernel instead of the LDS-DMA fast path, so that both are covered by parity tests. */
-void eavqa_debug_disable_fast_gemm(int disable);
-/* Experiment knob (host), bit fields of `units`: [7:0] start-up delay (x 8 x 64 cycles) of every other co-resident
- * workgroup of the 128 x 128 LDS-DMA kernel; [9:8] timing-only ablation variant (results wrong when non-zero);
- * [17:16] tile choice: 0 by shape, 1 never the 256 x 256 kernel, 2 always the 256 x 256 kernel (K % 64 == 0). */
-void eavqa_debug_gemm_stagger(int units);
-/* Test hook (host): non-zero keeps bf16 attention on the vector-ALU kernels instead of the matrix-core ones. */
-void eavqa_debug_attention_valu(int force);
-
 /* ----------------------------------------------------------- LayerNorm ---
  * torch.nn.LayerNorm over the last dim (ln_1/ln_2/ln_f HF:gpt2 :253-257,620;
  * self_attn_layer_norm/final_layer_norm HF:opt :196-205; CLIP layer_norm1/2, pre/post
@@ -212,9 +202,13 @@ int eavqa_build_labels(int mode, int B, int T, int L, const int64_t* input_ids, 
  * UNshifted (rows = B*S, row r = b*S+s is scored against labels[b, s+1]); or, with S == 0, `labels` is one
  * already-shifted label per row (int64 [B], B = number of rows; packed rows of eavqa_build_row_plan).
  * Writes row_loss/row_lse float32 [rows] (0 for ignored rows), then loss[0] = sum/count and
- * count[0] (deterministic tree reduction, no atomics). */
+ * count[0] (deterministic tree reduction, no atomics).  A label that is neither -100 nor in [0, V) makes loss[0] NaN
+ * (torch.nn.functional.cross_entropy asserts on the device there; nothing throws across this ABI). */
 int eavqa_ce_fwd(int B, int S, int V, const float* logits, int64_t ld, const int64_t* labels,
                  float* row_loss, float* row_lse, float* loss, float* count, void* stream);
+/* loss[0] = NaN when count[0] > capacity: the scored-row compaction (eavqa_select_rows) was sized from a host-side label
+ * count; an under-count would silently drop labelled rows, so it poisons the loss instead (no host synchronisation). */
+int eavqa_guard_count(const int32_t* count, int capacity, float* loss, void* stream);
 /* dlogits[r, v] = gscale[0] / count[0] * (softmax(logits[r])[v] - [v == label]) for kept rows, 0 for
  * ignored rows and for pad columns V..ldd-1 (`dtype` out). */
 int eavqa_ce_bwd(int dtype, int B, int S, int V, const float* logits, int64_t ld, const int64_t* labels,

@@ -1,0 +1,50 @@
+/*
+ * eavqa_test.h - TEST-ONLY entry points of libeavqa_hip.so (not part of the drop-in boundary of include/eavqa.h).
+ *
+ * eavqa_gemm / eavqa_attention_* choose a kernel from the shape.  The parity tests must cover every kernel on shapes
+ * where the dispatcher would pick another one, and tools/gemm_bench.py times individual kernels: the *_ex forms below take
+ * the choice as an ARGUMENT, so the library itself keeps no mutable state (the public forms pass 0).
+ */
+#ifndef EAVQA_TEST_H
+#define EAVQA_TEST_H
+
+#include "eavqa.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* eavqa_gemm with a kernel selector.  Bit fields of `knobs`:
+ *   [7:0]   start-up delay (x 8 x 64 cycles) of every other co-resident workgroup of the 128 x 128 LDS-DMA kernel (experiment)
+ *   [10:8]  timing-only ablation variant of that kernel (RESULTS ARE WRONG when non-zero)
+ *   [17:16] 256 x 256 kernel: 0 by shape, 1 never, 2 always (K % 64 == 0)
+ *   [21:20] 2 = 8-stage LDS ring (experiment)
+ *   [26:24] shaped tiles: 0 by cost model, 1 never, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192
+ *   [28]    general register-staged kernel instead of the LDS-DMA kernels (bf16, k-contiguous operands, K % 32 == 0) */
+int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
+                  const void* A, int64_t lda, const void* B, int64_t ldb,
+                  void* C, int64_t ldc, int out_f32, float alpha,
+                  const float* bias, int act,
+                  const void* aux_in, void* aux_out, int64_t ld_aux,
+                  const float* residual, int64_t ldr, void* stream, int knobs);
+
+/* eavqa_attention_fwd / _bwd with a path selector: bit 0 keeps bf16 on the vector-ALU kernels (instead of the matrix-core
+ * ones), bit 1 (backward) takes the dQ + dK/dV kernel pair even when the problem is one tile. */
+int eavqa_attention_fwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
+                           const void* q, int64_t ldq, const void* k, int64_t ldk,
+                           const void* v, int64_t ldv, void* o, int64_t ldo,
+                           int64_t q_batch_rows, int64_t kv_batch_rows,
+                           const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal, float scale,
+                           float* lse, void* stream, int path);
+int eavqa_attention_bwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
+                           const void* q, int64_t ldq, const void* k, int64_t ldk,
+                           const void* v, int64_t ldv, const void* o, int64_t ldo,
+                           const void* d_o, int64_t lddo,
+                           void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                           const int32_t* key_mask, const int32_t* cu_seqlens, int causal, float scale,
+                           const float* lse, float* delta, void* stream, int path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EAVQA_TEST_H */

@@ -1,4 +1,5 @@
-"""CPU: the C-ABI library builds, loads, and exports exactly what include/eavqa.h declares.
+"""CPU: the C-ABI library builds, loads, and exports exactly what include/eavqa.h (the drop-in boundary) and
+include/eavqa_test.h (test-only kernel selectors) declare.
 No compute call is made here (there is no GPU in the build container)."""
 import os
 import re
@@ -8,10 +9,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "eavqa.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(eavqa_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=("eavqa.h", "eavqa_test.h")):
+    out = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        out |= set(re.findall(r"\b(eavqa_[a-z0-9_]+)\s*\(", text))
+    return sorted(out)
 
 
 @pytest.fixture(scope="module")
@@ -24,6 +28,10 @@ def lib():
 def test_header_declares_the_expected_surface():
     syms = declared_symbols()
     assert "eavqa_gemm" in syms and "eavqa_attention_fwd" in syms and len(syms) >= 20
+    public = declared_symbols(("eavqa.h",))
+    # the drop-in boundary carries no test hooks and no process-global switches
+    assert not [n for n in public if "debug" in n or n.endswith("_ex")]
+    assert set(declared_symbols(("eavqa_test.h",))) - set(public) == {"eavqa_gemm_ex", "eavqa_attention_fwd_ex", "eavqa_attention_bwd_ex"}
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
@@ -32,6 +40,12 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, name), f"{name} declared in eavqa.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_library_exports_no_mutable_global_switches(lib):
+    """`no global mutable state` (include/eavqa.h conventions): the round-1 eavqa_debug_* setters are gone."""
+    for name in ("eavqa_debug_disable_fast_gemm", "eavqa_debug_gemm_stagger", "eavqa_debug_attention_valu"):
+        assert not hasattr(lib, name), name
 
 
 def test_abi_version_and_strerror(lib):

@@ -48,15 +48,13 @@ def gemm_path(request):
     """bf16 k-contiguous GEMMs take the 128x128 LDS-DMA kernel (K % 32 == 0) or the 256x256 one (K % 64 == 0, chosen by
     shape) or a shaped tile (128x80 ... 256x192, chosen by shape); run every case through the general kernel, the 128x128
     kernel and (forced) the 256x256 kernel and every shaped tile."""
-    from eavqa_amd import _lib
-    lib = _lib.load()
-    lib.eavqa_debug_disable_fast_gemm(int(request.param == "general"))
+    from eavqa_amd import ops
     big = 2 if request.param == "big" else 1
     shape = {"128x80": 2, "128x96": 3, "256x128": 4, "256x160": 5, "256x192": 6}.get(request.param, 1)
-    lib.eavqa_debug_gemm_stagger((big << 16) | (shape << 24))
+    # the selector travels with every call (eavqa_gemm_ex, include/eavqa_test.h): the library holds no state
+    ops.KernelSelect.gemm = (big << 16) | (shape << 24) | (int(request.param == "general") << 28)
     yield request.param
-    lib.eavqa_debug_disable_fast_gemm(0)
-    lib.eavqa_debug_gemm_stagger(0)
+    ops.KernelSelect.gemm = 0
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -191,10 +189,10 @@ def test_layernorm_bf16_input_rows_with_stride(ops):
 def attn_path(request):
     """bf16 attention with hd in {64,80,96,128} runs on the matrix cores (one-tile problems take the fused backward,
     "mfma_split" forces the dQ + dK/dV pair); run every case through all of them and the vector-ALU kernels."""
-    from eavqa_amd import _lib
-    _lib.load().eavqa_debug_attention_valu({"mfma": 0, "mfma_split": 2, "valu": 1}[request.param])
+    from eavqa_amd import ops
+    ops.KernelSelect.attention = {"mfma": 0, "mfma_split": 2, "valu": 1}[request.param]
     yield request.param
-    _lib.load().eavqa_debug_attention_valu(0)
+    ops.KernelSelect.attention = 0
 
 
 def attn_ref(q, k, v, key_mask, causal, scale):

@@ -44,8 +44,8 @@ def main():
     ap.add_argument("--cold", action="store_true", help="rotate over enough copies of the weight to defeat L2 + Infinity Cache")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
-    _lib.load().eavqa_debug_disable_fast_gemm(int(args.general))
-    _lib.load().eavqa_debug_gemm_stagger(args.stagger | (args.ablate << 8) | (args.big << 16) | (args.deep << 20) | (args.shape << 24))
+    ops.KernelSelect.gemm = (args.stagger | (args.ablate << 8) | (args.big << 16) | (args.deep << 20) | (args.shape << 24)
+                             | (int(args.general) << 28))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
     for M, N, K, what in SHAPES:
