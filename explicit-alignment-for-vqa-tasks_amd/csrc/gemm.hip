@@ -23,11 +23,12 @@ namespace {
 struct Knobs {
     int stagger;        // [7:0]   s_sleep units for odd co-resident blocks of the fast kernel (experiment)
     int ablate;         // [10:8]  timing-only ablation variant of the fast kernel (results wrong when non-zero)
+    int k64_mode;       // [15:12] full-line (BK = 64) family: 0 = by cost model, 1 = never (round-1 dispatch), 2.. force K64_SHAPES[id - 2]
     int big_mode;       // [17:16] 0 = 256 x 256 kernel by shape, 1 never, 2 always (K % 64 == 0)
     int deep;           // [21:20] 2 = force the 8-stage ring (experiment)
     int shape_mode;     // [26:24] 0 = shaped tiles by cost model, 1 never, 2.. force SHAPES[id - 2]
     bool disable_fast;  // [28]    general register-staged kernel on fast-path shapes (parity coverage of that kernel)
-    explicit Knobs(int k = 0) : stagger(k & 0xff), ablate((k >> 8) & 7), big_mode((k >> 16) & 3), deep((k >> 20) & 3),
+    explicit Knobs(int k = 0) : stagger(k & 0xff), ablate((k >> 8) & 7), k64_mode((k >> 12) & 15), big_mode((k >> 16) & 3), deep((k >> 20) & 3),
                                 shape_mode((k >> 24) & 7), disable_fast(((k >> 28) & 1) != 0) {}
 };
 
@@ -908,6 +909,18 @@ bool use_big(const GemmParams& p, const Knobs& kn) {
 }
 
 
+// ============================================== bf16 full-line tiles ===
+#include "gemm_k64.hip"
+
+// Modelled time (ns) of a K64 shape on this problem: workgroups on the fullest CU x (operand lines per K-step at the shape's
+// intake rate + its epilogue); co-resident workgroups share the CU's intake, so two per CU cost what two in a row cost.
+inline float k64_cost(const GemmParams& p, const K64Choice& c) {
+    const int tiles_m = (p.M + c.bm - 1) / c.bm, tiles_n = (p.N + c.bn - 1) / c.bn;
+    const GridPlan g = plan_grid(tiles_m, tiles_n, c.bm, c.bn);
+    const float rounds = float((g.per_xcd + 31) / 32);
+    return rounds * (c.rate * (c.bm + c.bn) * (p.K / 64) + 0.25f * c.bm * c.bn + 1500.f);
+}
+
 // ======================================================= bf16 skinny M ===
 // M <= 64 rows (a decode step: M = batch; the MLP mapper at batch 64): the GEMM is a weight-streaming problem, HBM
 // bound on B.  Each workgroup owns 16 output columns and its 8 waves split K; a wave loads its B fragment (16 rows x
@@ -1171,7 +1184,17 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     p.vec_bias = (reinterpret_cast<uintptr_t>(bias) % 16) == 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
+        if (a_kc && b_kc && (K % 64) == 0 && kn.k64_mode >= 2 && kn.k64_mode < 2 + N_K64) return K64_SHAPES[kn.k64_mode - 2].launch(p, s);
         if (a_kc && b_kc && !kn.disable_fast && M <= 64 && (K % 32) == 0 && N >= 64) return launch_skinny(p, s);
+        if (a_kc && b_kc && !kn.disable_fast && (K % 64) == 0 && kn.k64_mode != 1 && kn.shape_mode == 0 && kn.big_mode == 0) {
+            int pick = 0;
+            float best = k64_cost(p, K64_SHAPES[0]);
+            for (int i = 1; i < N_K64_AUTO; ++i) {
+                const float c = k64_cost(p, K64_SHAPES[i]);
+                if (c < best) { best = c; pick = i; }
+            }
+            return K64_SHAPES[pick].launch(p, s);
+        }
         if (a_kc && b_kc && !kn.disable_fast && (K % FBK) == 0) {
             if (kn.shape_mode >= 2 && kn.shape_mode < 7) return SHAPES[kn.shape_mode - 2].launch(p, s);
             const bool big_ok = (K % GBK) == 0 && kn.big_mode != 1;

@@ -249,6 +249,17 @@ class FrozenCausalLM:
         self.cfg.vocab = n
         self._bwd_ready = False
 
+    def load_token_embeddings(self, weight: Tensor) -> None:
+        """Replace the token embedding matrix (and the tied head) by ``weight`` [vocab, E] - e.g. the rows a reference
+        checkpoint holds after its ``resize_token_embeddings`` drew the new ones at random."""
+        if tuple(weight.shape) != tuple(self.wte.shape):
+            raise ValueError(f"token embedding shape {tuple(weight.shape)} does not match {tuple(self.wte.shape)}")
+        tied = self.head is self.wte
+        self.wte = self._T(weight)
+        if tied:
+            self.head = self.wte
+        self._bwd_ready = False
+
     # ---------------------------------------------------------------- forward
     def forward(self, prefix_rows: Optional[Tensor], src: Tensor, pos: Tensor, mask: Tensor, B: int, S: int, *,
                 labels: Optional[Tensor] = None, save: bool = False, logits: str = "none", pack: bool = False,

@@ -61,8 +61,9 @@ class ClipCapExecutor:
         self.model = model
         self.vision_encoder = vision_encoder
         if self.tokenizer is not None:
-            if getattr(self.tokenizer, "pad_token_id", None) is None:
-                self.tokenizer.pad_token = self.tokenizer.eos_token                         # :55
+            # unconditional, as the reference: a tokenizer that HAS a pad token (OPT: pad 1, eos 2) pads with eos too from here
+            # on, so the restored first-pad label (:146) is the eos id and generation's early stop sees it
+            self.tokenizer.pad_token = self.tokenizer.eos_token                             # :55
             self.model.gpt.resize_token_embeddings(len(self.tokenizer))                     # :56
         self.global_step = 0
         self.logged: Dict[str, Any] = {}
@@ -178,19 +179,35 @@ class ClipCapExecutor:
             self.grad_sync = GradSync(mapper.flat.grad, exchange=not factors)
         self.model.train()
         losses = []
+        pending = 0                                  # micro-batches whose gradients sit in the flat buffer
+
+        def apply():
+            nonlocal pending
+            self.grad_sync.start()
+            self.grad_sync.finish()
+            # Lightning divides every micro-batch loss by accumulate_grad_batches, also in the short last group of an epoch
+            self.optimizer.step(grad_scale=self.grad_sync.grad_scale / accumulate_grad_batches)
+            self.optimizer.zero_grad()
+            self.scheduler.step()
+            self.global_step += 1
+            pending = 0
+
         for batch_idx, batch in enumerate(batches):
             if max_steps is not None and self.global_step >= max_steps:
                 break
             loss = self.training_step(batch, batch_idx)["loss"]
             loss.backward()
             losses.append(loss.detach())
-            if (batch_idx + 1) % accumulate_grad_batches == 0:
-                self.grad_sync.start()
-                self.grad_sync.finish()
-                self.optimizer.step(grad_scale=self.grad_sync.grad_scale / accumulate_grad_batches)
+            pending += 1
+            if pending == accumulate_grad_batches:
+                apply()
+        if pending:
+            # the trailing micro-batches of the epoch: Lightning steps on the last batch whatever the remainder is;
+            # leaving them would also leak their gradients into the next fit() call
+            if max_steps is None or self.global_step < max_steps:
+                apply()
+            else:
                 self.optimizer.zero_grad()
-                self.scheduler.step()
-                self.global_step += 1
         return losses
 
     # ------------------------------------------------------------------ checkpoints (mapper only + LM identity)
@@ -207,6 +224,14 @@ class ClipCapExecutor:
         sd = ckpt.get("state_dict", ckpt)
         mapper = {k[len("model.clip_project."):]: v for k, v in sd.items() if k.startswith("model.clip_project.")}
         self.model.clip_project.load_state_dict(mapper, strict=True)
+        # a reference checkpoint carries the frozen LM too; the only part of it that differs from `model_version` is the token
+        # embedding grown by resize_token_embeddings (:56, rows drawn at random by HF): take it when its shape fits
+        for key in ("model.gpt.transformer.wte.weight", "model.gpt.model.decoder.embed_tokens.weight"):
+            if key in sd and tuple(sd[key].shape) == tuple(self.model.gpt.wte.shape):
+                self.model.gpt.load_token_embeddings(sd[key])
         self.global_step = int(ckpt.get("global_step", 0))
         if ckpt.get("optimizer") and self.optimizer is not None:
             self.optimizer.load_state_dict({k: (v.to(self.device) if torch.is_tensor(v) else v) for k, v in ckpt["optimizer"].items()})
+        if self.scheduler is not None:
+            # the reference builds its schedulers with last_epoch = global_step (:96-124): a resumed run continues the schedule
+            self.scheduler.resume(self.global_step)

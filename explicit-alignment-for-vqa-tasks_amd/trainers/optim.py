@@ -61,6 +61,12 @@ class ConstantScheduleWithWarmup:
         self.n += 1
         self._apply()
 
+    def resume(self, global_step: int) -> None:
+        """Continue from ``global_step`` optimiser steps (the reference passes ``last_epoch=self.global_step`` when it
+        builds the scheduler, clipcap_exector.py:96-124)."""
+        self.n = int(global_step)
+        self._apply()
+
     def get_last_lr(self):
         return [g["lr"] for g in self.opt.param_groups]
 

@@ -369,7 +369,233 @@ def vqa_eval_golden():
     print(f"wrote vqa_eval.json: {len(cases)} strings, {len(qa)} questions, overall {ev.accuracy['overall']}")
 
 
+def dropin_golden():
+    """Fixtures for the REAL construction path of the reference executor (src/trainers/clipcap_exector.py:52-56):
+    ``ModelClass(**model_args)`` -> ``GPT2LMHeadModel.from_pretrained(model_version)`` (src/models/clipcap.py:252) ->
+    ``self.model.gpt.resize_token_embeddings(len(self.tokenizer))`` after the <BOS> token was added (:55-56).
+
+    * ``hf_gpt2_tiny/`` and ``hf_opt_tiny/``: HF-format directories (config.json + model.safetensors, DATA written by
+      ``save_pretrained``) of the same seeded 2-layer models whose weights the ``clipcap_*_mlp.npz`` fixtures hold, so a test
+      can hand ``model_version=<dir>`` to the executor and compare with those fixtures;
+    * ``resize_gpt2.npz``: the reference model after ``resize_token_embeddings(V + 1)`` on a VQA-style batch whose answers are
+      introduced by the NEW token id V: the grown embedding matrix, logits [B, L+T, V+1], loss, mapper gradients and
+      generated ids."""
+    import json
+    import shutil
+    clipcap, _ = _import_reference()
+    from transformers import GPT2Config, GPT2LMHeadModel, OPTConfig, OPTForCausalLM
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    import oracle
+    tmp = tempfile.mkdtemp(prefix="eavqa_dropin_")
+
+    def keep_dir(src, name):
+        dst = os.path.join(HERE, name)
+        os.makedirs(dst, exist_ok=True)
+        for f in ("config.json", "model.safetensors"):
+            shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+        print(f"wrote {name}/: " + ", ".join(f"{f} {os.path.getsize(os.path.join(dst, f))/1024:.1f} KiB" for f in ("config.json", "model.safetensors")))
+
+    # the tiny GPT-2 of main() (same seed, same config -> same weights; checked against the committed fixture below)
+    V, E, NLAY, NH, L, D = 320, 64, 2, 4, 4, 24
+    torch.manual_seed(2021)
+    cfg = GPT2Config(vocab_size=V, n_embd=E, n_layer=NLAY, n_head=NH, n_positions=64, bos_token_id=V - 1, eos_token_id=V - 1,
+                     attn_implementation="eager", resid_pdrop=0.0, embd_pdrop=0.0, attn_pdrop=0.0)
+    d_gpt2 = os.path.join(tmp, "gpt2")
+    GPT2LMHeadModel(cfg).save_pretrained(d_gpt2)
+    with np.load(os.path.join(HERE, "clipcap_gpt2_mlp.npz")) as z:
+        fix = {k: z[k] for k in z.files}
+    torch.manual_seed(7)
+    model = clipcap.ClipCaptionPrefix(prefix_length=L, clip_length=3, prefix_size=D, num_layers=2, mapping_type="mlp", model_version=d_gpt2)
+    model.gpt.config._attn_implementation = "eager"
+    for k, v in model.gpt.state_dict().items():
+        assert np.array_equal(v.numpy(), fix["lm." + k]), f"tiny GPT-2 differs from the committed fixture at {k}"
+    for k, v in model.clip_project.state_dict().items():
+        assert np.array_equal(v.numpy(), fix["map." + k]), k
+    keep_dir(d_gpt2, "hf_gpt2_tiny")
+
+    # the reference executor's two lines: a tokenizer that gained "<BOS>" -> len V + 1
+    torch.manual_seed(3)
+    model.gpt.resize_token_embeddings(V + 1)
+    bos, pad = V, V - 1
+    gen = torch.Generator().manual_seed(99)
+    B, T = 4, 10
+    ids = torch.randint(0, V - 2, (B, T), generator=gen)
+    mask = torch.zeros(B, T, dtype=torch.long)
+    for b, (ql, al) in enumerate(((3, 2), (5, 1), (2, 3), (4, 4))):
+        ids[b, ql] = bos
+        end = ql + 1 + al
+        ids[b, end:] = pad
+        mask[b, :end] = 1
+    labels = oracle.label_mask_vqa(ids, pad, bos)            # the executor's rule (restated; the executor cannot be imported)
+    prefix = torch.randn(B, D, generator=gen)
+    model.train()
+    out = model(question_tokens=ids, prefix=prefix, question_mask=mask, labels=labels, pad_token_id=pad)
+    out.loss.backward()
+    grads = {"g." + n: p.grad.numpy() for n, p in model.clip_project.named_parameters()}
+    model.eval()
+    gq = ids[:, :6].clone()
+    gm = mask[:, :6].clone()
+    with torch.no_grad():
+        gen_ids = model.generate(question_tokens=gq, prefix=prefix, question_mask=gm, max_length=5, pad_token_id=pad, eos_token_id=pad)
+    save("resize_gpt2.npz", cfg=np.array([V, E, NLAY, NH, 64, L, D]), new_vocab=np.array(V + 1), bos_id=np.array(bos), pad_id=np.array(pad),
+         wte=model.gpt.transformer.wte.weight.detach().numpy(), ids=ids.numpy(), mask=mask.numpy(), labels=labels.numpy(),
+         prefix=prefix.numpy(), logits=out.logits.detach().numpy(), loss=out.loss.detach().numpy(), gen_ids=gq.numpy(), gen_mask=gm.numpy(),
+         gen=np.array(gen_ids), **_np(model.clip_project.state_dict(), "map."), **grads)
+
+    # the tiny OPT of main()
+    with np.load(os.path.join(HERE, "clipcap_opt_mlp.npz")) as z:
+        fix = {k: z[k] for k in z.files}
+    torch.manual_seed(11)
+    V, E, NLAY, NH, FFN = 336, 64, 2, 4, 96
+    ocfg = OPTConfig(vocab_size=V, hidden_size=E, num_hidden_layers=NLAY, num_attention_heads=NH, ffn_dim=FFN, max_position_embeddings=64,
+                     word_embed_proj_dim=E, pad_token_id=1, bos_token_id=2, eos_token_id=2, attn_implementation="eager", dropout=0.0,
+                     attention_dropout=0.0)
+    opt = OPTForCausalLM(ocfg).eval()
+    for k, v in opt.state_dict().items():
+        assert np.array_equal(v.numpy(), fix["lm." + k]), f"tiny OPT differs from the committed fixture at {k}"
+    d_opt = os.path.join(tmp, "opt")
+    opt.save_pretrained(d_opt)
+    keep_dir(d_opt, "hf_opt_tiny")
+    shutil.rmtree(tmp, ignore_errors=True)
+
+
+
+MP_WORDS = ["question", "answer", "what", "color", "is", "the", "boys", "hat", "red", "man", "wearing", "a", "shirt", "no", "where", "he",
+            "looking", "down", "combine", "facts", "and", "this", "two", "dogs", "yes", "how", "many", "are", "there", "?", ":", "."]
+
+
+def build_word_tokenizer(words, eos="</s>", pad=None):
+    """A real HuggingFace fast tokenizer built offline from a word list (WordLevel model, lower-cased, whitespace / punctuation
+    split): what stands in for GPT2Tokenizer / AutoTokenizer.from_pretrained(name), which needs the network."""
+    from tokenizers import Tokenizer, models, normalizers, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<unk>": 0, eos: 1}
+    if pad:
+        vocab[pad] = 2
+    for w in words:
+        vocab.setdefault(w, len(vocab))
+    tk = Tokenizer(models.WordLevel(vocab, unk_token="<unk>"))
+    tk.normalizer = normalizers.Lowercase()
+    tk.pre_tokenizer = pre_tokenizers.Whitespace()
+    return PreTrainedTokenizerFast(tokenizer_object=tk, unk_token="<unk>", eos_token=eos, pad_token=pad)
+
+
+def module_parser_golden():
+    """Batch dicts produced by the REFERENCE ``ModuleParser`` (src/data_loader_manager/module_parser.py, loaded by file path;
+    ``easydict`` / ``clip`` stubbed in memory as for the formatter) and the reference's ``collate_fn`` flow
+    (src/data_loader_manager/datasets/vqa2_datasets.py:94-181, restated around the reference's own ``parse_modules`` /
+    ``post_processing`` because the dataset module imports cv2 / timm) for the two module configurations of the causal path:
+    training (``configs/vqa2/clip_cap.jsonnet:46-75``: QAInput + EmbeddingInput) and few-shot generation
+    (``configs/vqa2/few_shot_vqa_hotpotqa.jsonnet:46-56``: QInput + EmbeddingInput), with and without permutations."""
+    import importlib.util
+    import json
+    clip = types.ModuleType("clip")
+    sys.modules.setdefault("clip", clip)
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            elif isinstance(v, list):
+                v = [EasyDict(x) if isinstance(x, dict) and not isinstance(x, EasyDict) else x for x in v]
+            super().__setitem__(k, v)
+        __getattr__ = dict.__getitem__
+        __setattr__ = __setitem__
+    ed.EasyDict = EasyDict
+    sys.modules.setdefault("easydict", ed)
+    EasyDict = sys.modules["easydict"].EasyDict
+    sys.path.insert(0, "/root/reference/src")
+    spec = importlib.util.spec_from_file_location("ref_module_parser", "/root/reference/src/data_loader_manager/module_parser.py")
+    mp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mp)
+
+    examples = [dict(question_id=508840006, img_key=508840, question="What color is the boys hat?", gold_answer="red"),
+                dict(question_id=135938002, img_key=135938, question="Is the man wearing a shirt?", gold_answer="no"),
+                dict(question_id=7, img_key=77, question="How many dogs are there?", gold_answer="two")]
+    items = [dict(question_id=262148000, img_key=262148, question="Where is he looking?", gold_answer="down", answers=["down"] * 10),
+             dict(question_id=262148001, img_key=135938, question="Is the man wearing a hat?", gold_answer="yes", answers=["yes", "no"])]
+    gen = torch.Generator().manual_seed(5)
+    D = 6
+    store = {str(k): torch.randn(1, D, generator=gen).numpy() for k in (508840, 135938, 77, 262148)}
+
+    def run(module_cfg, additional, num_shots, special_tokens, n_sentinels):
+        tok = build_word_tokenizer(MP_WORDS)
+        # data_loader_wrapper.py:57-62 (+ the sentinel tokens a causal LM needs, registered in reverse order)
+        extra = [f"<extra_id_{i}>" for i in reversed(range(n_sentinels))]
+        st = dict(special_tokens)
+        own = list(getattr(tok, "additional_special_tokens", None) or getattr(tok, "extra_special_tokens", None) or [])   # renamed in transformers 5
+        st["additional_special_tokens"] = own + st.get("additional_special_tokens", []) + extra
+        tok.add_special_tokens(st)
+        tok.pad_token = tok.eos_token                                     # clipcap_exector.py:55
+        cfg = EasyDict(data_loader=EasyDict(additional=EasyDict(additional)), model_config=EasyDict(module_cfg))
+        parser = mp.ModuleParser()
+        parser.config, parser.tokenizer, parser.decoder_tokenizer = cfg, tok, tok
+        batch = []
+        for it in items:                                                  # vqa2_datasets.py:65-91
+            ctx = [] if num_shots == 0 else [EasyDict(e) for e in examples][-num_shots:]
+            embs = [store[str(e.img_key)] for e in ctx] + [store[str(it["img_key"])]]
+            batch.append(EasyDict(question_id=it["question_id"], question=it["question"], gold_answer=it["gold_answer"],
+                                  answers=it["answers"], clip_embedding=embs, in_context_examples=ctx))
+        out = {}
+        for kind in ("input", "decoder_input", "output"):                 # vqa2_datasets.py:105-157
+            spec_ = cfg.model_config[kind + "_modules"]
+            data = {}
+            for sample in batch:
+                for key, value in parser.parse_modules(sample, spec_.module_list, type=kind).items():
+                    data.setdefault(key, []).append(value)
+            out.update(parser.post_processing(EasyDict(data), spec_.postprocess_module_list))
+        js = {}
+        for k, v in out.items():
+            js[k] = v.tolist() if torch.is_tensor(v) else v
+        return dict(module_cfg=module_cfg, additional=additional, num_shots=num_shots, special_tokens=special_tokens,
+                    n_sentinels=n_sentinels, vocab_size=len(tok), bos_token_id=tok.bos_token_id, pad_token_id=tok.pad_token_id,
+                    sentinel_ids=[tok.convert_tokens_to_ids(f"<extra_id_{i}>") for i in range(n_sentinels)], batch=js)
+
+    sep = {"start": "question:", "end": "answer:"}
+    train_cfg = dict(
+        input_modules=dict(module_list=[dict(type="QAInput", option="default", separation_tokens=sep), dict(type="EmbeddingInput", option="default")],
+                           postprocess_module_list=[dict(type="PostProcessInputTokenization", option="default"),
+                                                    dict(type="PostProcessClipEmbeddings", option="default")]),
+        decoder_input_modules=dict(module_list=[dict(type="QuestionInput", option="default", separation_tokens=sep)],
+                                   postprocess_module_list=[dict(type="PostProcessInputTokenization", option="generation")]),
+        output_modules=dict(module_list=[dict(type="GenerationOutput", option="default")],
+                            postprocess_module_list=[dict(type="PostProcessOutputTokenization", option="default")]))
+    fewshot_cfg = dict(
+        input_modules=dict(module_list=[dict(type="QInput", option="hotpotqa", separation_tokens={"start": "", "end": ""}),
+                                        dict(type="EmbeddingInput", option="default")],
+                           postprocess_module_list=[dict(type="PostProcessClipEmbeddings", option="default"),
+                                                    dict(type="PostProcessInputTokenization", option="generation")]),
+        decoder_input_modules=dict(module_list=[], postprocess_module_list=[]),
+        output_modules=dict(module_list=[dict(type="GenerationOutput", option="default")],
+                            postprocess_module_list=[dict(type="PostProcessOutputTokenization", option="default")]))
+    base_add = dict(max_source_length=64, max_decoder_source_length=64, max_target_length=8, pass_examples_through_encoder_one_at_a_time=0,
+                    sample_templates=0, ensemble_one_shots=0, num_permutations_of_in_context_examples=0)
+    cases = [
+        dict(name="train_qa", **run(train_cfg, dict(base_add, num_shots=0), 0, {"bos_token": "<BOS>", "additional_special_tokens": []}, 0)),
+        dict(name="fewshot_2", **run(fewshot_cfg, dict(base_add, num_shots=2), 2, {"additional_special_tokens": []}, 3)),
+        dict(name="zeroshot", **run(fewshot_cfg, dict(base_add, num_shots=0), 0, {"additional_special_tokens": []}, 1)),
+        dict(name="fewshot_3_perm2", **run(fewshot_cfg, dict(base_add, num_shots=3, num_permutations_of_in_context_examples=2), 3,
+                                           {"additional_special_tokens": []}, 4)),
+    ]
+    out = dict(words=MP_WORDS, examples=examples, items=items, store={k: v.tolist() for k, v in store.items()}, cases=cases)
+    with open(os.path.join(HERE, "module_parser.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(f"wrote module_parser.json: {len(cases)} cases; " + "; ".join(f"{c['name']}: keys {sorted(c['batch'])}" for c in cases[:2]))
+
+
 if __name__ == "__main__":
+    if "--module-parser-only" in sys.argv:
+        module_parser_golden()
+        sys.exit(0)
+    if "--dropin-only" in sys.argv:
+        dropin_golden()
+        sys.exit(0)
     if "--vqa-eval-only" in sys.argv:
         vqa_eval_golden()
         sys.exit(0)
@@ -379,3 +605,5 @@ if __name__ == "__main__":
         main()
         formatter_golden()
         vqa_eval_golden()
+        dropin_golden()
+        module_parser_golden()

@@ -150,6 +150,49 @@ def test_gemm_large_bf16_statistical(ops, gemm_path):
     assert rel < 1e-5, rel   # products exact in fp32, only summation order differs
 
 
+K64_NAMES = ["128x128", "128x80", "128x96", "256x128", "256x160", "256x192", "256x256", "256x256db", "128x128s3"]
+
+
+@pytest.mark.parametrize("shape_id", range(len(K64_NAMES)), ids=K64_NAMES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1, 64, 64), (333, 1000, 320), (1943, 1280, 1280), (257, 5120, 128), (70, 200, 3840),
+                                   (2050, 90, 192), (512, 512, 64 * 37)])
+def test_gemm_full_line_family(ops, shape_id, M, N, K):
+    """Every tile shape of the BK = 64 full-cache-line family (csrc/gemm_k64.hip), forced through eavqa_gemm_ex, on ragged M / N,
+    one-step and many-step K: raw products against fp64, then the full epilogue (bias, activation, aux_out, residual, bf16 out)."""
+    a = rnd(M, K, dtype=torch.bfloat16, seed=21)
+    b = rnd(N, K, dtype=torch.bfloat16, seed=22)
+    ref = (a.double() @ b.double().T).float()
+    ops.KernelSelect.gemm = (2 + shape_id) << 12
+    try:
+        out = ops.gemm(a.to(DEV), b.to(DEV), out_f32=True)
+        bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
+        aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        out2 = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act="gelu_new", aux_out=aux, residual=res.to(DEV), out_f32=True, alpha=0.25)
+        out3 = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act="relu")
+        torch.cuda.synchronize()
+    finally:
+        ops.KernelSelect.gemm = 0
+    assert (out.cpu() - ref).abs().max().item() <= 1e-3 * math.sqrt(K)
+    pre = ref * 0.25 + bias
+    assert (aux.float().cpu() - pre).abs().max().item() <= 2e-2 * max(1.0, pre.abs().max().item())
+    assert (out2.cpu() - (oracle.gelu_new(pre) + res)).abs().max().item() <= 1e-3 * math.sqrt(K)
+    want3 = torch.relu(ref + bias)
+    assert out3.dtype == torch.bfloat16 and (out3.float().cpu() - want3).abs().max().item() <= 1e-2 * max(1.0, want3.abs().max().item())
+
+
+def test_gemm_full_line_family_is_the_default_dispatch(ops):
+    """With no selector a k-contiguous bf16 GEMM with K % 64 == 0 takes the full-line family; results equal the forced tile's
+    bit for bit (same kernel), whichever tile the cost model picks."""
+    a, b = rnd(1943, 1280, dtype=torch.bfloat16, seed=31).to(DEV), rnd(1280, 1280, dtype=torch.bfloat16, seed=32).to(DEV)
+    auto = ops.gemm(a, b, out_f32=True)
+    same = []
+    for i in range(7):
+        ops.KernelSelect.gemm = (2 + i) << 12
+        same.append(bool(torch.equal(auto, ops.gemm(a, b, out_f32=True))))
+    ops.KernelSelect.gemm = 0
+    assert any(same), same
+
+
 # --------------------------------------------------------------------------- LayerNorm
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("rows,cols", [(5, 64), (37, 768), (130, 1280), (3, 4096), (2, 8192)])

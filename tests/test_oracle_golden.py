@@ -177,3 +177,32 @@ def test_adamw_step_matches_torch():
         opt.step()
         oracle.adamw_step(p, g, m, v, step, 1e-4)
         assert torch.allclose(p, ref.detach(), atol=1e-7)
+
+
+def test_oracle_reproduces_the_reference_after_resize_token_embeddings():
+    """``resize_gpt2.npz``: the reference model after ``gpt.resize_token_embeddings(V + 1)`` (clipcap_exector.py:55-56) on a
+    VQA-style batch whose answers start at the NEW token id V: the oracle on the grown matrix gives the reference's
+    logits [B, L+T, V+1], loss, mapper gradients and greedy ids; the new row is the mean of the old ones (what this build's
+    ``FrozenCausalLM.resize_token_embeddings`` writes) to within HF's 1e-9-covariance draw."""
+    z = load_golden("resize_gpt2.npz")
+    zl = load_golden("clipcap_gpt2_mlp.npz")
+    V, E, NLAY, NH, NPOS, L, D = [int(v) for v in z["cfg"]]
+    sd = {k[3:]: T(v) for k, v in zl.items() if k.startswith("lm.")}
+    assert np.array_equal(z["wte"][:V], zl["lm.transformer.wte.weight"])
+    assert np.abs(z["wte"][V] - z["wte"][:V].mean(0)).max() <= 1e-5
+    sd["transformer.wte.weight"] = T(z["wte"])
+    sd.pop("lm_head.weight", None)
+    mapper = {k[4:]: T(v).clone().requires_grad_(True) for k, v in z.items() if k.startswith("map.")}
+    cfg, mcfg = dict(arch="gpt2", n_layer=NLAY, n_head=NH), dict(prefix_length=L, mapping_type="mlp")
+    assert np.array_equal(oracle.label_mask_vqa(T(z["ids"]), int(z["pad_id"]), int(z["bos_id"])).numpy(), z["labels"])
+    loss, logits = oracle.clipcap_forward(sd, cfg, mapper, mcfg, T(z["ids"]), T(z["prefix"]), T(z["mask"]), T(z["labels"]))
+    assert logits.shape[-1] == V + 1
+    assert (logits.detach() - T(z["logits"])).abs().max().item() <= 1e-4
+    assert abs(loss.item() - float(z["loss"])) <= 1e-5
+    loss.backward()
+    for k, p in mapper.items():
+        assert (p.grad - T(z["g." + k])).abs().max().item() <= 1e-5, k
+    with torch.no_grad():
+        ids = oracle.clipcap_generate(sd, cfg, {k: v.detach() for k, v in mapper.items()}, mcfg, T(z["gen_ids"]), T(z["prefix"]),
+                                      T(z["gen_mask"]), max_length=5, pad_token_id=int(z["pad_id"]), eos_token_id=int(z["pad_id"]))
+    assert ids == z["gen"].tolist()

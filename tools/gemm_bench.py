@@ -39,12 +39,13 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation variant of the fast kernel (wrong results)")
     ap.add_argument("--big", type=int, default=0, help="0 auto, 1 never 256x256, 2 always 256x256")
     ap.add_argument("--shape", type=int, default=0, help="0 auto, 1 never a shaped tile, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192")
+    ap.add_argument("--k64", type=int, default=0, help="full-line family: 0 by cost model, 1 never (round-1 kernels), 2.. force K64_SHAPES[id - 2]")
     ap.add_argument("--deep", type=int, default=0, help="8-stage ring: 0 auto, 1 never, 2 always")
     ap.add_argument("--check", action="store_true", help="compare the result with a torch matmul")
     ap.add_argument("--cold", action="store_true", help="rotate over enough copies of the weight to defeat L2 + Infinity Cache")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
-    ops.KernelSelect.gemm = (args.stagger | (args.ablate << 8) | (args.big << 16) | (args.deep << 20) | (args.shape << 24)
+    ops.KernelSelect.gemm = (args.stagger | (args.ablate << 8) | (args.k64 << 12) | (args.big << 16) | (args.deep << 20) | (args.shape << 24)
                              | (int(args.general) << 28))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
