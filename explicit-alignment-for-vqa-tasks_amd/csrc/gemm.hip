@@ -21,15 +21,15 @@ namespace {
 
 // Kernel-selection knobs of eavqa_gemm_ex (include/eavqa_test.h), decoded per call: the library keeps no mutable state.
 struct Knobs {
-    int stagger;        // [7:0]   s_sleep units for odd co-resident blocks of the fast kernel (experiment)
-    int ablate;         // [10:8]  timing-only ablation variant of the fast kernel (results wrong when non-zero)
-    int k64_mode;       // [15:12] full-line (BK = 64) family: 0 = by cost model, 1 = never (round-1 dispatch), 2.. force K64_SHAPES[id - 2]
-    int big_mode;       // [17:16] 0 = 256 x 256 kernel by shape, 1 never, 2 always (K % 64 == 0)
-    int deep;           // [21:20] 2 = force the 8-stage ring (experiment)
-    int shape_mode;     // [26:24] 0 = shaped tiles by cost model, 1 never, 2.. force SHAPES[id - 2]
-    bool disable_fast;  // [28]    general register-staged kernel on fast-path shapes (parity coverage of that kernel)
-    explicit Knobs(int k = 0) : stagger(k & 0xff), ablate((k >> 8) & 7), k64_mode((k >> 12) & 15), big_mode((k >> 16) & 3), deep((k >> 20) & 3),
-                                shape_mode((k >> 24) & 7), disable_fast(((k >> 28) & 1) != 0) {}
+    int stagger;        // [3:0]   s_sleep units for odd co-resident blocks of the round-1 128 x 128 kernel (experiment)
+    int ablate;         // [6:4]   timing-only ablation variant of that kernel (results wrong when non-zero)
+    bool disable_fast;  // [7]     general register-staged kernel on fast-path shapes (parity coverage of that kernel)
+    int k64_mode;       // [13:8]  full-line (BK = 64) family: 0 = by cost model, 1 = never (round-1 dispatch), 2.. force K64_SHAPES[id - 2]
+    int big_mode;       // [15:14] round-1 256 x 256 kernel: 0 by shape, 1 never, 2 always (K % 64 == 0)
+    int deep;           // [17:16] 2 = force the 8-stage ring of the round-1 128 x 128 kernel (experiment)
+    int shape_mode;     // [20:18] round-1 shaped tiles: 0 by cost model, 1 never, 2.. force SHAPES[id - 2]
+    explicit Knobs(int k = 0) : stagger(k & 15), ablate((k >> 4) & 7), disable_fast(((k >> 7) & 1) != 0), k64_mode((k >> 8) & 63),
+                                big_mode((k >> 14) & 3), deep((k >> 16) & 3), shape_mode((k >> 18) & 7) {}
 };
 
 struct GemmParams {

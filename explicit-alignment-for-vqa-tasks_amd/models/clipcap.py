@@ -37,14 +37,26 @@ class FlatParams:
     """Owns flat master / grad / shadow buffers; module parameters are views into ``master``."""
 
     ALIGN = 8  # elements: keeps every view 16-byte aligned in bf16 and 32-byte aligned in fp32
+    SHARD_ALIGN = 4096   # the matrix region is a multiple of this: it cuts evenly into world x buckets shards of aligned length
 
     def __init__(self, named_shapes: List[Tuple[str, Tuple[int, ...]]], device, compute_dtype: torch.dtype):
+        """Layout: first every 1-D parameter (biases, LayerNorm affine: read in float32 by the kernels, ``f``), then the
+        matrices (read through the compute-dtype shadow, ``w``).  ``small_numel`` is the length of the first region: the sharded
+        optimiser (trainers/optim.py ``ShardedAdamW``) keeps that region replicated and shards only the matrices."""
         self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
         off = 0
-        for name, shape in named_shapes:
+        ordered = [ns for ns in named_shapes if len(ns[1]) <= 1] + [ns for ns in named_shapes if len(ns[1]) > 1]
+        self.small_numel = 0
+        for name, shape in ordered:
+            if len(shape) > 1 and self.small_numel == 0:
+                self.small_numel = off
             n = int(math.prod(shape))
             self.offsets[name] = (off, tuple(shape))
             off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        if self.small_numel == 0:
+            self.small_numel = off if all(len(sh) <= 1 for _, sh in ordered) else 0
+        big = off - self.small_numel
+        off = self.small_numel + (big + self.SHARD_ALIGN - 1) // self.SHARD_ALIGN * self.SHARD_ALIGN
         self.numel = off
         self.compute_dtype = compute_dtype
         self.master = torch.zeros(off, device=device, dtype=torch.float32)

@@ -98,3 +98,164 @@ class CosineAnnealing(ConstantScheduleWithWarmup):
         for g in self.opt.param_groups:
             base = g["initial_lr"]
             g["lr"] = self.eta_min + (base - self.eta_min) * (1 + self._math.cos(self._math.pi * self.n / self.t_max)) / 2
+
+
+class ShardedAdamW:
+    """Data-parallel mapper update with the optimiser SHARDED over the ranks (ZeRO-1 shaped for xGMI), for mappers whose gradient
+    is too large to all-reduce and whose weight gradient is not a product of a few per-sample factors (the transformer mapper),
+    or whose factor exchange would repeat too much work (the 8.64 B-parameter MLP mapper of BASELINE configs[4],
+    src/models/clipcap.py:256-262).  Per step, on a side stream, bucket by bucket:
+
+        reduce-scatter(sum) of the bucket's flat fp32 gradient        -> every rank holds 1/world of the summed gradient
+        fused AdamW on that shard (fp32 master + moments of the shard) -> updated master shard + its compute-dtype copy
+        all-gather of the compute-dtype shards                          -> every rank has the whole updated operand copy
+
+    Bytes per rank and step: (world-1)/world x (4 + 2) B/parameter instead of the all-reduce's 2 x (world-1)/world x 4, optimiser
+    traffic and moment memory 1/world; xGMI is point-to-point, so both collectives are per-link bound and the
+    bucket pipeline keeps one collective in flight while the previous bucket's AdamW runs.  The 1-D parameters (biases, LayerNorm
+    affine: ``FlatParams.small_numel`` leading elements, read in fp32 by the kernels) stay replicated: one small all-reduce and
+    a redundant update on every rank.
+
+    Layout of the matrix region [small, numel): ``n_buckets`` contiguous buckets of ``world x piece`` elements; rank r owns
+    [r x piece, (r+1) x piece) of every bucket, so each collective works on one contiguous range (in place for the gather).
+    ``adamw`` is the update kernel (``ops.adamw``; the CPU tests inject a torch restatement - the product path has no CPU fallback)."""
+
+    def __init__(self, flat, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, *, group=None,
+                 n_buckets: int = 4, adamw=None):
+        import torch.distributed as dist
+        self.flat, self.group = flat, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.param_groups = [dict(lr=lr, initial_lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)]
+        self.adamw = adamw if adamw is not None else ops.adamw
+        self.small = flat.small_numel
+        big = flat.numel - self.small
+        while n_buckets > 1 and big % (n_buckets * self.world * flat.ALIGN):
+            n_buckets -= 1
+        if big % (n_buckets * self.world * flat.ALIGN):
+            raise ValueError(f"matrix region of {big} elements does not cut into {self.world} aligned shards")
+        self.n_buckets = n_buckets
+        self.piece = big // (n_buckets * self.world)
+        dev = flat.master.device
+        self.m_small = torch.zeros(self.small, device=dev)
+        self.v_small = torch.zeros(self.small, device=dev)
+        self.m = torch.zeros(n_buckets * self.piece, device=dev)
+        self.v = torch.zeros(n_buckets * self.piece, device=dev)
+        self.gshard = torch.empty(n_buckets * self.piece, device=dev)
+        self.step_count = 0
+        self.stream = torch.cuda.Stream() if (flat.master.is_cuda and self.world > 1) else None
+        self._busy = False
+
+    @property
+    def grad_scale(self) -> float:
+        return 1.0 / self.world
+
+    def _bucket(self, b: int):
+        lo = self.small + b * self.world * self.piece
+        return lo, lo + self.world * self.piece, lo + self.rank * self.piece
+
+    def _run(self, grad_scale: float) -> None:
+        import torch.distributed as dist
+        fl, g = self.flat, self.param_groups[0]
+        self.step_count += 1
+        kw = dict(step=self.step_count, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                  grad_scale=grad_scale)
+        lowp = fl.shadow is not fl.master
+        multi = self.world > 1
+        if self.small:
+            if multi:
+                dist.all_reduce(fl.grad[:self.small], op=dist.ReduceOp.SUM, group=self.group)
+            self.adamw(fl.master[:self.small], fl.grad[:self.small], self.m_small, self.v_small, shadow=fl.shadow[:self.small] if lowp else None, **kw)
+        for b in range(self.n_buckets):
+            lo, hi, mine = self._bucket(b)
+            gs = self.gshard[b * self.piece:(b + 1) * self.piece]
+            if multi:
+                dist.reduce_scatter_tensor(gs, fl.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+            else:
+                gs = fl.grad[lo:hi]
+            self.adamw(fl.master[mine:mine + self.piece], gs, self.m[b * self.piece:(b + 1) * self.piece], self.v[b * self.piece:(b + 1) * self.piece],
+                       shadow=fl.shadow[mine:mine + self.piece] if lowp else None, **kw)
+            if multi:
+                # in place: rank r's input is its own slice of the output
+                dist.all_gather_into_tensor(fl.shadow[lo:hi], fl.shadow[mine:mine + self.piece], group=self.group)
+        fl.mark_shadow_fresh()
+
+    def start(self, grad_scale: float = None) -> None:
+        """Enqueue exchange + update behind everything queued on the current stream (call right after backward)."""
+        scale = self.grad_scale if grad_scale is None else grad_scale
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._run(scale)
+        else:
+            self._run(scale)
+        self._busy = True
+
+    def finish(self) -> None:
+        """Make the current stream wait for the updated operand copy (call before the next mapper forward)."""
+        if self._busy and self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self._busy = False
+
+    def step(self, grad_scale: float = None) -> None:
+        """Optimiser-style entry: exchange + update + wait."""
+        self.start(grad_scale)
+        self.finish()
+
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        self.flat.grad_live = False
+
+    def gather_master(self) -> torch.Tensor:
+        """The whole fp32 master copy on every rank (checkpoints): non-owned shards are stale between steps in bf16 mode."""
+        import torch.distributed as dist
+        fl = self.flat
+        if self.world > 1 and fl.shadow is not fl.master:
+            for b in range(self.n_buckets):
+                lo, hi, mine = self._bucket(b)
+                dist.all_gather_into_tensor(fl.master[lo:hi], fl.master[mine:mine + self.piece], group=self.group)
+        return fl.master
+
+    def state_dict(self):
+        return dict(step=self.step_count, m=self.m, v=self.v, m_small=self.m_small, v_small=self.v_small, param_groups=self.param_groups,
+                    world=self.world, rank=self.rank, n_buckets=self.n_buckets)
+
+    def load_state_dict(self, sd) -> None:
+        if (sd["world"], sd["rank"], sd["n_buckets"]) != (self.world, self.rank, self.n_buckets):
+            raise ValueError("sharded optimiser state belongs to another world size / rank / bucket count")
+        self.step_count = int(sd["step"])
+        for name in ("m", "v", "m_small", "v_small"):
+            getattr(self, name).copy_(sd[name])
+        self.param_groups = sd["param_groups"]
+
+
+# ----------------------------------------------------------------------------------------------------------------- exchange choice
+# Measured / documented rates behind the rule below (DESIGN.md section 7): the mapper wgrad GEMM at K = world x B runs at ~0.4
+# PFLOP/s (tools/gemm_bench.py, transposed-factor path), fused AdamW streams 30 B/parameter at ~4.4 TB/s, and a ring collective
+# over xGMI is bound by ONE link (~153 GB/s, SURVEY.md 5; 0.7 achieved assumed until a multi-GPU box measures it).
+WGRAD_FLOPS, ADAMW_BW, LINK_BW = 0.4e15, 4.4e12, 0.7 * 153e9
+
+
+def dp_exchange_costs(n_params: int, n_factor_params: int, per_gpu_batch: int, world: int, links: int = 1):
+    """Modelled seconds per step of the three exchanges for a mapper of ``n_params`` parameters, ``n_factor_params`` of them in
+    Linear layers whose weight gradient is an outer product of per-sample factors (all of an MLP mapper, none of a transformer
+    mapper's attention / LayerNorm - its Linear layers see L tokens per sample, so their factors are L times larger):
+      factors   all-gather of the factors (negligible) + the weight gradient of the GLOBAL batch on every rank
+                (world x the local wgrad FLOPs) + the full AdamW pass on every rank
+      sharded   reduce-scatter fp32 + all-gather bf16 over `links` links + 1/world of the AdamW pass
+      allreduce ring all-reduce of the fp32 gradient + the full AdamW pass"""
+    w = max(world, 1)
+    frac = (w - 1) / w
+    adam = 30.0 * n_params / ADAMW_BW
+    costs = {"allreduce": 2 * frac * 4.0 * n_params / (links * LINK_BW) + adam,
+             "sharded": frac * 6.0 * n_params / (links * LINK_BW) + adam / w}
+    if n_factor_params == n_params:
+        costs["factors"] = (w - 1) * 2.0 * per_gpu_batch * n_factor_params / WGRAD_FLOPS + adam
+    return costs
+
+
+def choose_dp_exchange(n_params: int, n_factor_params: int, per_gpu_batch: int, world: int, links: int = 1) -> str:
+    """The cheapest exchange under :func:`dp_exchange_costs` ("factors" | "sharded" | "allreduce"); ``world == 1`` -> "none"."""
+    if world <= 1:
+        return "none"
+    costs = dp_exchange_costs(n_params, n_factor_params, per_gpu_batch, world, links)
+    return min(costs, key=costs.get)

@@ -15,12 +15,14 @@ extern "C" {
 #endif
 
 /* eavqa_gemm with a kernel selector.  Bit fields of `knobs`:
- *   [7:0]   start-up delay (x 8 x 64 cycles) of every other co-resident workgroup of the 128 x 128 LDS-DMA kernel (experiment)
- *   [10:8]  timing-only ablation variant of that kernel (RESULTS ARE WRONG when non-zero)
- *   [17:16] 256 x 256 kernel: 0 by shape, 1 never, 2 always (K % 64 == 0)
- *   [21:20] 2 = 8-stage LDS ring (experiment)
- *   [26:24] shaped tiles: 0 by cost model, 1 never, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192
- *   [28]    general register-staged kernel instead of the LDS-DMA kernels (bf16, k-contiguous operands, K % 32 == 0) */
+ *   [3:0]   start-up delay (x 8 x 64 cycles) of every other co-resident workgroup of the round-1 128 x 128 LDS-DMA kernel (experiment)
+ *   [6:4]   timing-only ablation variant of that kernel (RESULTS ARE WRONG when non-zero)
+ *   [7]     general register-staged kernel instead of the LDS-DMA kernels (bf16, k-contiguous operands, K % 32 == 0)
+ *   [13:8]  full-line (BK = 64) family of csrc/gemm_k64.hip: 0 by cost model, 1 never (round-1 dispatch), 2.. force entry id - 2 of
+ *           K64_SHAPES (tile shape x plain / loader-consumer specialised; the table is in that file)
+ *   [15:14] round-1 256 x 256 kernel: 0 by shape, 1 never, 2 always (K % 64 == 0)
+ *   [17:16] 2 = 8-stage LDS ring of the round-1 128 x 128 kernel (experiment)
+ *   [20:18] round-1 shaped tiles: 0 by cost model, 1 never, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192 */
 int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                   const void* A, int64_t lda, const void* B, int64_t ldb,
                   void* C, int64_t ldc, int out_f32, float alpha,

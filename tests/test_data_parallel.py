@@ -86,3 +86,79 @@ def test_gradsync_single_rank_is_a_noop():
     s = GradSync(buf, 1)
     s.start(); s.finish()
     assert s.grad_scale == 1.0 and torch.equal(buf, torch.arange(5.0))
+
+
+def _cpu_adamw(param, grad, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale, shadow=None):
+    """torch restatement of eavqa_adamw for the CPU tests (the product default, ops.adamw, has no CPU path)."""
+    import oracle
+    oracle.adamw_step(param, grad * grad_scale, m, v, step, lr, beta1, beta2, eps, weight_decay)
+    if shadow is not None:
+        shadow.copy_(param.to(shadow.dtype))
+
+
+def _sharded_worker(rank, world, port, results):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      EAVQA_DIST_BACKEND="gloo")
+    import oracle
+    from eavqa_amd.models.clipcap import FlatParams
+    from eavqa_amd.trainers.data_parallel import init_from_env
+    from eavqa_amd.trainers.optim import ShardedAdamW
+    init_from_env()
+    out = {}
+    for cdt in (torch.float32, torch.bfloat16):
+        shapes = [("linear.weight", (24, 16)), ("linear.bias", (24,)), ("norm.weight", (16,)), ("attn.weight", (48, 16)), ("prefix_const", (5, 16))]
+        flat = FlatParams(shapes, "cpu", cdt)
+        g0 = torch.Generator().manual_seed(1)
+        init = torch.randn(flat.numel, generator=g0)
+        flat.master.copy_(init)
+        if flat.shadow is not flat.master:
+            flat.shadow.copy_(init.to(cdt))
+        opt = ShardedAdamW(flat, lr=0.05, group=None, n_buckets=2, adamw=_cpu_adamw)
+        assert opt.world == world and opt.n_buckets == 2 and flat.small_numel == 24 + 16
+        # reference: plain AdamW on the cross-rank MEAN gradient, whole buffer
+        ref_p, ref_m, ref_v = init.clone(), torch.zeros(flat.numel), torch.zeros(flat.numel)
+        ok = True
+        for step in range(1, 4):
+            grads = [torch.randn(flat.numel, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)]
+            flat.grad.copy_(grads[rank])
+            opt.start()
+            opt.finish()
+            oracle.adamw_step(ref_p, sum(grads) / world, ref_m, ref_v, step, 0.05)
+            # every rank holds the whole updated operand copy; the fp32 master is exact on the owned shards and the small region
+            tol = 1e-6 if cdt == torch.float32 else 1e-2
+            ok = ok and bool((flat.shadow.float() - ref_p).abs().max().item() <= tol * max(1.0, ref_p.abs().max().item()))
+            ok = ok and bool(torch.allclose(flat.master[:flat.small_numel], ref_p[:flat.small_numel], atol=1e-6))
+            for b in range(opt.n_buckets):
+                lo, hi, mine = opt._bucket(b)
+                ok = ok and bool(torch.allclose(flat.master[mine:mine + opt.piece], ref_p[mine:mine + opt.piece], atol=1e-6))
+        full = opt.gather_master()
+        ok = ok and bool(torch.allclose(full, ref_p, atol=1e-6))
+        out[str(cdt)] = ok
+    results[rank] = out
+    dist.destroy_process_group()
+
+
+def test_sharded_adamw_two_ranks_gloo():
+    """Reduce-scatter + sharded AdamW + all-gather (the exchange for the transformer mapper / very large mappers) gives, on every
+    rank, the parameters of plain AdamW on the mean gradient."""
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        results = mgr.dict()
+        mp.spawn(_sharded_worker, args=(world, port, results), nprocs=world, join=True)
+        res = dict(results)
+    assert all(all(v.values()) for v in res.values()) and len(res) == world, res
+
+
+def test_exchange_choice_rule():
+    """gradient factors while the whole-batch weight gradient + full AdamW pass is cheaper than moving 6 B per
+    parameter over one xGMI link; the sharded optimiser for mappers without per-sample factors."""
+    from eavqa_amd.trainers.optim import choose_dp_exchange, dp_exchange_costs
+    assert choose_dp_exchange(85_000_000, 85_000_000, 64, 1) == "none"
+    assert choose_dp_exchange(85_000_000, 85_000_000, 64, 8) == "factors"               # cfg2 MLP mapper
+    assert choose_dp_exchange(218_000_000, 218_000_000, 64, 8) == "factors"             # cfg3
+    assert choose_dp_exchange(1_170_000_000, 0, 32, 8) == "sharded"                     # cfg5 transformer mapper: no factor path
+    c = dp_exchange_costs(8_640_000_000, 8_640_000_000, 32, 8)
+    assert c["factors"] < c["sharded"] < c["allreduce"]
+    c7 = dp_exchange_costs(8_640_000_000, 8_640_000_000, 32, 8, links=7)
+    assert c7["sharded"] < c7["factors"]                                                # a direct 7-link algorithm would flip it

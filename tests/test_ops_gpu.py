@@ -52,7 +52,7 @@ def gemm_path(request):
     big = 2 if request.param == "big" else 1
     shape = {"128x80": 2, "128x96": 3, "256x128": 4, "256x160": 5, "256x192": 6}.get(request.param, 1)
     # the selector travels with every call (eavqa_gemm_ex, include/eavqa_test.h): the library holds no state
-    ops.KernelSelect.gemm = (big << 16) | (shape << 24) | (int(request.param == "general") << 28)
+    ops.KernelSelect.gemm = (big << 14) | (shape << 18) | (int(request.param == "general") << 7)
     yield request.param
     ops.KernelSelect.gemm = 0
 
@@ -150,7 +150,9 @@ def test_gemm_large_bf16_statistical(ops, gemm_path):
     assert rel < 1e-5, rel   # products exact in fp32, only summation order differs
 
 
-K64_NAMES = ["128x128", "128x80", "128x96", "256x128", "256x160", "256x192", "256x256", "256x256db", "128x128s3"]
+K64_NAMES = ["128x128", "128x80", "128x96", "256x128", "256x160", "256x192", "256x256", "256x256db", "128x128s3",
+             "s128x80l2", "s128x80l4", "s128x128l4", "s256x128l4", "s256x160l4", "s128x80n4", "s128x96", "s256x192", "s256x256", "s128x128n3",
+             "s256x128fat", "s128x256"]      # s*: loader / consumer specialised
 
 
 @pytest.mark.parametrize("shape_id", range(len(K64_NAMES)), ids=K64_NAMES)
@@ -162,7 +164,7 @@ def test_gemm_full_line_family(ops, shape_id, M, N, K):
     a = rnd(M, K, dtype=torch.bfloat16, seed=21)
     b = rnd(N, K, dtype=torch.bfloat16, seed=22)
     ref = (a.double() @ b.double().T).float()
-    ops.KernelSelect.gemm = (2 + shape_id) << 12
+    ops.KernelSelect.gemm = (2 + shape_id) << 8
     try:
         out = ops.gemm(a.to(DEV), b.to(DEV), out_f32=True)
         bias, res = rnd(N, seed=23), rnd(M, N, seed=24)
@@ -187,7 +189,7 @@ def test_gemm_full_line_family_is_the_default_dispatch(ops):
     auto = ops.gemm(a, b, out_f32=True)
     same = []
     for i in range(7):
-        ops.KernelSelect.gemm = (2 + i) << 12
+        ops.KernelSelect.gemm = (2 + i) << 8
         same.append(bool(torch.equal(auto, ops.gemm(a, b, out_f32=True))))
     ops.KernelSelect.gemm = 0
     assert any(same), same

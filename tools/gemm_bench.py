@@ -17,6 +17,7 @@ from eavqa_amd import _lib, ops
 SHAPES = [  # (M, N, K, what)
     (32, 7680, 2560, "decode qkv"), (32, 2560, 2560, "decode proj"), (32, 10240, 2560, "decode fc1"), (32, 2560, 10240, "decode fc2"),
     (32, 50272, 2560, "decode lm_head"), (64, 12800, 6400, "mlp fc2 fwd"),
+    (1943, 1280, 64, "epi proj"), (1943, 3840, 64, "epi qkv"), (1943, 5120, 64, "epi fc1"), (1943, 1280, 3840, "packed da"),
     (2688, 1280, 32, "fixed K=32"), (2688, 1280, 320, "fixed K=320"), (1943, 1280, 1280, "packed proj"), (1943, 3840, 1280, "packed qkv"),
     (1943, 5120, 1280, "packed fc1"), (1943, 1280, 5120, "packed fc2"),
     (2688, 3840, 1280, "qkv fwd"), (2688, 1280, 1280, "proj fwd / dctx"), (2688, 5120, 1280, "fc1 fwd / du"),
@@ -45,8 +46,8 @@ def main():
     ap.add_argument("--cold", action="store_true", help="rotate over enough copies of the weight to defeat L2 + Infinity Cache")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
-    ops.KernelSelect.gemm = (args.stagger | (args.ablate << 8) | (args.k64 << 12) | (args.big << 16) | (args.deep << 20) | (args.shape << 24)
-                             | (int(args.general) << 28))
+    ops.KernelSelect.gemm = (args.stagger | (args.ablate << 4) | (int(args.general) << 7) | (args.k64 << 8) | (args.big << 14) | (args.deep << 16)
+                             | (args.shape << 18))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
     for M, N, K, what in SHAPES:
