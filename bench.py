@@ -51,21 +51,23 @@ def flops_per_sample(vit_cfg, lm_cfg, L, S, D):
     return vit + 3 * mapper + 2 * lm
 
 
-def build_workload(name, dtype, device, rank):
+def build_workload(name, dtype, device, rank, mapping_type=None):
     from eavqa_amd.data.synthetic import cc_batch
     from eavqa_amd.models.clip_vit import KNOWN_VITS, ClipVisionEncoder, random_init_vit_state_dict
     from eavqa_amd.models.clipcap import ClipCaptionPrefix
     from eavqa_amd.models.lm import KNOWN_CONFIGS, FrozenCausalLM, LMConfig, random_init_state_dict
     from eavqa_amd.trainers.optim import FusedAdamW
 
-    w = WORKLOADS[name]
+    w = dict(WORKLOADS[name])
+    if mapping_type:
+        w["mapping_type"] = mapping_type
     vcfg = KNOWN_VITS[w["vit"]]
     lcfg = LMConfig.from_hf_dict(KNOWN_CONFIGS[w["lm"]])
     vit = ClipVisionEncoder(vcfg, random_init_vit_state_dict(vcfg, 2021, device), dtype, device)
     lm = FrozenCausalLM(lcfg, random_init_state_dict(lcfg, 2021, device), dtype, device)
     torch.manual_seed(2021)   # mapper init = nn.Linear default under the reference seed
-    model = ClipCaptionPrefix(prefix_length=w["prefix_length"], prefix_size=vcfg.proj, mapping_type=w["mapping_type"],
-                              lm=lm, dtype=dtype, device=device).train()
+    model = ClipCaptionPrefix(prefix_length=w["prefix_length"], clip_length=w.get("clip_length", w["prefix_length"]), prefix_size=vcfg.proj,
+                              mapping_type=w["mapping_type"], lm=lm, dtype=dtype, device=device).train()
     opt = FusedAdamW(model.clip_project.flat, lr=1e-4)
     pad = lcfg.eos_token_id
     batch = cc_batch(w["batch"], lcfg.vocab, pad, image_size=vcfg.image, max_len=w["text_len"], seed=2021 + rank, device="cpu")
@@ -95,7 +97,8 @@ class Stepper:
     def _apply_update(self):
         if self.pending_update:
             self.sync.finish()
-            self.opt.step(grad_scale=self.sync.grad_scale)
+            if self.sync is not self.opt:            # the sharded optimiser has already updated its shard behind the reduce-scatter
+                self.opt.step(grad_scale=self.sync.grad_scale)
             self.opt.zero_grad()
             self.pending_update = False
 
@@ -162,11 +165,15 @@ def fewshot_qps(dtype, device, reps=3):
     b = fewshot_batch(f["batch"], lcfg.vocab, f["shots"], f["seg_len"], sentinel, image_size=vcfg.image, device=device)
     B, n_img = f["batch"], f["shots"] + 1
 
-    def run():
+    def run(marks=None):
         px = b["pixel_values"]
+        if marks is not None:
+            marks.append(("start", _event()))
         emb = vit.encode_image(px.reshape(B * n_img, *px.shape[2:])).view(B, n_img, -1)
+        if marks is not None:
+            marks.append(("encode", _event()))
         return model.generate_fewshot(b["input_ids"], emb, b["attention_mask"], num_shots=f["shots"], special_token_id=sentinel,
-                                      max_length=f["new_tokens"], pad_token_id=lcfg.pad_token_id, eos_token_id=None)
+                                      max_length=f["new_tokens"], pad_token_id=lcfg.pad_token_id, eos_token_id=None, marks=marks)
 
     run()
     torch.cuda.synchronize()
@@ -176,10 +183,55 @@ def fewshot_qps(dtype, device, reps=3):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     assert len(out) == B and len(out[0]) == f["new_tokens"]
+    # per-phase roofline of one more, instrumented batch (HIP events on the launch stream; a ~40 ms head start of queued work
+    # keeps host latency out of the brackets, as in gemm_roofline)
+    blk = torch.randn(8192, 8192, device=device).to(torch.bfloat16)
+    blk_c = torch.empty(8192, 8192, device=device, dtype=torch.bfloat16)
+    for _ in range(40):
+        ops_gemm(blk, blk, out=blk_c)
+    marks = []
+    run(marks)
+    torch.cuda.synchronize()
+    ev = dict(marks)
+    ms = dict(encode=ev["start"].elapsed_time(ev["encode"]), prefill=ev["encode"].elapsed_time(ev["prefill"]),
+              decode=ev["prefill"].elapsed_time(ev["decode"]))
+    L, S0 = f["prefix_length"], n_img * (1 + f["seg_len"]) + (f["prefix_length"] - 1) * n_img
+    E, F, V, NL = lcfg.n_embd, lcfg.ffn, lcfg.vocab, lcfg.n_layer
+    W, N = vcfg.width, vcfg.n_patch + 1
+    vit_flop = B * n_img * (vcfg.n_layer * (2 * N * (4 * W * W + 2 * W * vcfg.mlp) + 4 * N * N * W) + 2 * vcfg.n_patch * 3 * vcfg.patch ** 2 * W + 2 * W * vcfg.proj)
+    H_map = E * L // 2
+    prefill_flop = B * (NL * (2 * S0 * (4 * E * E + 2 * E * F) + 4 * S0 * S0 * E) + 2 * E * V) + B * n_img * 2 * (vcfg.proj * H_map + H_map * E * L)
+    steps = f["new_tokens"] - 1                                  # the first token comes out of the prefill
+    weight_bytes = 2.0 * (NL * (4 * E * E + 2 * E * F) + E * V)
+    kv_bytes = sum(2.0 * NL * B * (S0 + t + 1) * E * 2 for t in range(steps)) / max(steps, 1)      # K and V rows read per step, bf16
+    roof = [
+        dict(phase="vit_encode", bound="mfma", kernel="eavqa_gemm (ViT-L/14 tower) + eavqa_attn_mfma::fwd", ms=round(ms["encode"], 3),
+             achieved=round(vit_flop / (ms["encode"] * 1e-3) / 1e12, 1), peak=2500.0, unit="TFLOP/s"),
+        dict(phase="mapper_prefill", bound="mfma", kernel="eavqa_lm_block_forward (prefill: eavqa_gemm + attention over 150 positions)",
+             ms=round(ms["prefill"], 3), achieved=round(prefill_flop / (ms["prefill"] * 1e-3) / 1e12, 1), peak=2500.0, unit="TFLOP/s"),
+        dict(phase="decode", bound="hbm", kernel="eavqa_lm_block_forward (decode: gemm_bf16_splitk + attn_decode), weights + KV cache read once per step",
+             ms=round(ms["decode"], 3), ms_per_step=round(ms["decode"] / max(steps, 1), 3), steps=steps,
+             achieved=round((weight_bytes + kv_bytes) * steps / (ms["decode"] * 1e-3) / 1e9, 1), peak=8000.0, unit="GB/s",
+             bytes_per_step=round(weight_bytes + kv_bytes)),
+    ]
+    for r in roof:
+        r["frac"] = round(r["achieved"] / r["peak"], 4)
     del model, lm, vit
     torch.cuda.empty_cache()
     return {"metric": "fewshot_vqa_questions_per_sec", "value": round(B / dt, 2), "unit": "questions/s", "ms_per_batch": round(dt * 1e3, 2),
-            "config": {"workload": f["desc"], "batch": B, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "kv_cache": True}}
+            "config": {"workload": f["desc"], "batch": B, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "kv_cache": True},
+            "roofline": roof}
+
+
+def _event():
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def ops_gemm(a, b, out):
+    from eavqa_amd import ops
+    return ops.gemm(a, b, out=out)
 
 
 def cpu_baseline(name, n_samples, threads):
@@ -241,8 +293,11 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--cpu-baseline-samples", type=int, default=64, help="0 disables the CPU baseline leg (default: one whole step of the workload, ~10 s)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--dp-exchange", choices=["factors", "allreduce"], default="factors",
-                    help="N > 1: all-gather the MLP mapper's gradient factors (default) or all-reduce its flat gradient")
+    ap.add_argument("--dp-exchange", choices=["auto", "factors", "allreduce", "sharded"], default="auto",
+                    help="N > 1: 'factors' all-gathers the MLP mapper's gradient factors, 'sharded' = reduce-scatter + sharded AdamW + "
+                         "all-gather, 'allreduce' = flat gradient all-reduce; 'auto' takes the cheapest under the cost model of "
+                         "eavqa_amd.trainers.optim.choose_dp_exchange (DESIGN.md section 7)")
+    ap.add_argument("--mapping-type", choices=["mlp", "transformer"], default=None, help="override the workload's mapper")
     ap.add_argument("--no-overlap", action="store_true", help="run the CLIP encode on the main stream (no cross-step pipelining)")
     ap.add_argument("--no-fewshot", action="store_true", help="skip the few-shot generate leg (metric M2, reported under 'extra')")
     args = ap.parse_args()
@@ -264,14 +319,28 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
     log(f"building workload {args.workload} ({args.dtype}) on {device}")
-    w, vcfg, lcfg, vit, model, opt, batch, pad = build_workload(args.workload, dtype, device, rank)
+    w, vcfg, lcfg, vit, model, opt, batch, pad = build_workload(args.workload, dtype, device, rank, args.mapping_type)
     torch.cuda.synchronize()
     log("workload built")
-    # N > 1: the MLP mapper exchanges gradient FACTORS (all-gather of a few MB) instead of all-reducing 340 MB of gradients
-    factors = world > 1 and args.dp_exchange == "factors" and hasattr(model.clip_project, "dp_factor_exchange")
+    # N > 1: which exchange carries the mapper gradient
+    from eavqa_amd.trainers.optim import ShardedAdamW, choose_dp_exchange
+    flat = model.clip_project.flat
+    has_factors = hasattr(model.clip_project, "dp_factor_exchange")
+    exchange = args.dp_exchange
+    if world == 1:
+        exchange = "none"
+    elif exchange == "auto":
+        exchange = choose_dp_exchange(flat.numel, flat.numel if has_factors else 0, w["batch"], world)
+    if exchange == "factors" and not has_factors:
+        raise SystemExit("--dp-exchange factors needs the MLP mapper")
+    factors = exchange == "factors"
     if factors:
         model.clip_project.dp_factor_exchange = True
-    sync = GradSync(model.clip_project.flat.grad, world, exchange=not factors)
+    if exchange == "sharded":
+        opt = ShardedAdamW(flat, lr=1e-4)            # exchange + update in one object (start / finish)
+        sync = opt
+    else:
+        sync = GradSync(flat.grad, world, exchange=not factors)
     stepper = Stepper(vit, model, opt, batch, pad, sync, overlap_vit=not args.no_overlap)
 
     def barrier():
@@ -333,7 +402,11 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {w['desc']}; per-GPU batch {B}, S={S}; fwd+bwd+AdamW; random-init weights",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
-                       **({"dp_exchange": "mapper gradient factors (all-gather)" if factors else "flat gradient all-reduce"} if world > 1 else {}),
+                       **({"dp_exchange": {"factors": "mapper gradient factors (all-gather; whole-batch weight gradient on every rank)",
+                                           "sharded": "reduce-scatter + sharded AdamW + all-gather of the bf16 operand copy",
+                                           "allreduce": "flat gradient all-reduce"}[exchange],
+                           "dp_exchange_model_ms": {k: round(v * 1e3, 2) for k, v in __import__("eavqa_amd.trainers.optim", fromlist=["x"]).dp_exchange_costs(
+                               flat.numel, flat.numel if has_factors else 0, w["batch"], world).items()}} if world > 1 else {}),
                        "algorithmic_gflop_per_sample": round(fps / 1e9, 1),
                        "step_tflops": round(value * fps / 1e12, 1), "final_loss": round(float(loss.item()), 4)},
             "roofline": roof, "cpu_baseline": cpu, "extra": extra,

@@ -54,6 +54,8 @@ SIGNATURES = {
     "eavqa_patchify": [i32, i32, i32, i32, ptr, ptr, i64, ptr],
     "eavqa_vit_assemble": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, i64, ptr],
     "eavqa_cast_rows": [i32, i32, i64, ptr, i64, ptr, i64, ptr],
+    "eavqa_quantize_rows_fp8": [i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr],
+    "eavqa_gemm_fp8": [i32, i32, i32, ptr, i64, ptr, ptr, i64, f32, ptr, i64, i32, f32, ptr, i32, ptr, ptr, i64, ptr, i64, ptr, i32],
 }
 class LMLayer(C.Structure):
     """``eavqa_lm_layer_t``."""

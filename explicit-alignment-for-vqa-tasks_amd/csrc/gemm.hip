@@ -35,6 +35,7 @@ struct Knobs {
 struct GemmParams {
     const void* A; const void* B; void* C;
     const float* bias; const void* aux_in; void* aux_out; const float* residual;
+    const float* row_scale;        // fp8 path: per-row dequantisation scale of A (multiplies alpha), else NULL
     int M, N, K;
     int64_t lda, ldb, ldc, ld_aux, ldr;
     int act, out_f32;
@@ -96,8 +97,9 @@ __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* 
         const float4 a = *reinterpret_cast<const float4*>(&Cs[row * G::PITCH + c4]);
         float v[4] = {a.x, a.y, a.z, a.w};
         const bool full = FULL || (n + 3 < p.N);
+        const float al = p.row_scale ? p.alpha * p.row_scale[m] : p.alpha;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = p.alpha * v[j] + bias4[j];
+        for (int j = 0; j < 4; ++j) v[j] = al * v[j] + bias4[j];
         if (aux_out) {
             T* q = aux_out + (int64_t)m * p.ld_aux + n;
             if (FULL || (full && p.vec_aux)) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
@@ -912,14 +914,18 @@ bool use_big(const GemmParams& p, const Knobs& kn) {
 // ============================================== bf16 full-line tiles ===
 #include "gemm_k64.hip"
 
-// Modelled time (ns) of a K64 shape on this problem: workgroups on the fullest CU x (operand lines per K-step at the shape's
-// intake rate + its epilogue); co-resident workgroups share the CU's intake, so two per CU cost what two in a row cost.
+// Dispatcher's model of a specialised tile on this problem (ns): a fixed part (launch ramp, first tile's round trip, C staging
+// and stores) + K-steps x rows per step x the tile's rate, times the workgroups the fullest CU receives.  Calibrated on MI355X
+// (profiles/round2_gemm_k64.md): 4-consumer tiles take in a 128-byte operand row per 1.56 ns, 8-consumer tiles per 1.95 ns (they
+// are close to their MFMA time), 128 x 128 per 1.73 ns; fixed ~4.5 us + 0.1 ns per output element of the tile.
 inline float k64_cost(const GemmParams& p, const K64Choice& c) {
     const int tiles_m = (p.M + c.bm - 1) / c.bm, tiles_n = (p.N + c.bn - 1) / c.bn;
     const GridPlan g = plan_grid(tiles_m, tiles_n, c.bm, c.bn);
     const float rounds = float((g.per_xcd + 31) / 32);
-    return rounds * (c.rate * (c.bm + c.bn) * (p.K / 64) + 0.25f * c.bm * c.bn + 1500.f);
+    return rounds * (c.rate * (c.bm + c.bn) * (p.K / 64) + 0.1f * c.bm * c.bn) + 4500.f;
 }
+
+#include "gemm_fp8.hip"
 
 // ======================================================= bf16 skinny M ===
 // M <= 64 rows (a decode step: M = batch; the MLP mapper at batch 64): the GEMM is a weight-streaming problem, HBM
@@ -1169,7 +1175,7 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     if (residual && ldr < N) return EAVQA_E_ARG;
 
     GemmParams p;
-    p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = nullptr;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
     p.act = act; p.out_f32 = out_f32; p.alpha = alpha;
     p.tiles_m = (M + BM - 1) / BM;
@@ -1185,14 +1191,23 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
         if (a_kc && b_kc && (K % 64) == 0 && kn.k64_mode >= 2 && kn.k64_mode < 2 + N_K64) return K64_SHAPES[kn.k64_mode - 2].launch(p, s);
-        if (a_kc && b_kc && !kn.disable_fast && M <= 64 && (K % 32) == 0 && N >= 64) return launch_skinny(p, s);
-        if (a_kc && b_kc && !kn.disable_fast && (K % 64) == 0 && kn.k64_mode != 1 && kn.shape_mode == 0 && kn.big_mode == 0) {
-            int pick = 0;
-            float best = k64_cost(p, K64_SHAPES[0]);
+        if (a_kc && b_kc && !kn.disable_fast && M <= 64 && (K % 32) == 0 && N >= 64 && (kn.k64_mode == 1 || (K % 64) != 0)) return launch_skinny(p, s);
+        // Default dispatch (K % 64 == 0): the loader / consumer specialised full-line tile the cost model ranks first, or the
+        // round-1 256 x 256 kernel where the model says its 1/128 B-per-FLOP intensity wins (problems with hundreds of such tiles:
+        // the CLIP tower, few-shot prefill, lm_head forward).  M <= 64 weight-streaming shapes take the same route.
+        // Problems with more than one 256 x 256 tile per CU keep the round-1 dispatcher below (calibrated on exactly those shapes).
+        const bool many_big_tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) >= 256;
+        if (a_kc && b_kc && !kn.disable_fast && (K % 64) == 0 && kn.k64_mode != 1 && kn.shape_mode == 0 && kn.big_mode == 0 && !many_big_tiles) {
+            int pick = K64_AUTO[0];
+            float best = k64_cost(p, K64_SHAPES[pick]);
             for (int i = 1; i < N_K64_AUTO; ++i) {
-                const float c = k64_cost(p, K64_SHAPES[i]);
-                if (c < best) { best = c; pick = i; }
+                const float c = k64_cost(p, K64_SHAPES[K64_AUTO[i]]);
+                if (c < best) { best = c; pick = K64_AUTO[i]; }
             }
+            // round-1 256 x 256 kernel: 2.99 ns per 128-byte row and 64-deep K-step of its 512 rows, ~6 us fixed (square 4k / fc1 fwd)
+            const GridPlan gb = plan_grid((M + GBM - 1) / GBM, (N + GBN - 1) / GBN, GBM, GBN);
+            const float big_cost = float((gb.per_xcd + 31) / 32) * 2.99f * 512.f * (K / 64) + 6000.f;
+            if (M > 64 && big_cost < best) return launch_big(p, s);
             return K64_SHAPES[pick].launch(p, s);
         }
         if (a_kc && b_kc && !kn.disable_fast && (K % FBK) == 0) {
@@ -1231,4 +1246,61 @@ extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                           const float* residual, int64_t ldr, void* stream) {
     return eavqa_gemm_ex(dtype, a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, out_f32, alpha, bias, act, aux_in, aux_out, ld_aux,
                          residual, ldr, stream, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- fp8 entry points
+extern "C" int eavqa_quantize_rows_fp8(int dtype, int rows, int cols, const void* x, int64_t ldx, void* out, int64_t ld_out,
+                                       float* row_scale, void* stream) {
+    if (!x || !out || !row_scale || rows <= 0 || cols <= 0) return EAVQA_E_ARG;
+    if (cols % 4) return EAVQA_E_SHAPE;
+    if (ldx % 4 || ld_out % 4 || ldx < cols || ld_out < cols) return EAVQA_E_ALIGN;
+    if ((reinterpret_cast<uintptr_t>(x) & 7u) || (reinterpret_cast<uintptr_t>(out) & 3u)) return EAVQA_E_ALIGN;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_BF16)
+        hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, cols, reinterpret_cast<const bf16_t*>(x), ldx,
+                           reinterpret_cast<unsigned char*>(out), ld_out, row_scale);
+    else if (dtype == EAVQA_F32)
+        hipLaunchKernelGGL(quantize_rows_fp8_kernel<float>, dim3(rows), dim3(256), 0, s, cols, reinterpret_cast<const float*>(x), ldx,
+                           reinterpret_cast<unsigned char*>(out), ld_out, row_scale);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_gemm_fp8(int M, int N, int K, const void* A, int64_t lda, const float* a_row_scale, const void* B, int64_t ldb,
+                              float b_scale, void* C, int64_t ldc, int out_f32, float alpha, const float* bias, int act,
+                              const void* aux_in, void* aux_out, int64_t ld_aux, const float* residual, int64_t ldr, void* stream, int tile) {
+    if (!A || !B || !C || !a_row_scale) return EAVQA_E_ARG;
+    if (M <= 0 || N <= 0 || K <= 0) return EAVQA_E_ARG;
+    if (act < EAVQA_ACT_NONE || act > EAVQA_ACT_QUICK_GELU) return EAVQA_E_DTYPE;
+    if (K % 128) return EAVQA_E_SHAPE;
+    if (lda % 16 || ldb % 16 || !eavqa_aligned16(A) || !eavqa_aligned16(B)) return EAVQA_E_ALIGN;
+    if (lda < K || ldb < K || ldc < N) return EAVQA_E_ARG;
+    if ((aux_in || aux_out) && ld_aux < N) return EAVQA_E_ARG;
+    if (residual && ldr < N) return EAVQA_E_ARG;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = a_row_scale;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
+    p.act = act; p.out_f32 = out_f32; p.alpha = alpha * b_scale;
+    p.tiles_m = (M + BM - 1) / BM;
+    p.tiles_n = (N + BN - 1) / BN;
+    auto vec_ok = [](const void* ptr, int64_t ld, int bytes_per_elem) {
+        return ((reinterpret_cast<uintptr_t>(ptr) % (4 * bytes_per_elem)) == 0) && (ld % 4 == 0);
+    };
+    p.vec_c = vec_ok(C, ldc, out_f32 ? 4 : 2);
+    p.vec_aux = vec_ok(aux_in ? aux_in : aux_out, ld_aux, 2);
+    p.vec_res = vec_ok(residual, ldr, 4);
+    p.vec_bias = (reinterpret_cast<uintptr_t>(bias) % 16) == 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (tile > 0 && tile <= N_FP8) return FP8_SHAPES[tile - 1].launch(p, s);
+    // same cost model as the bf16 specialised tiles: a stage row is 128 bytes there and here
+    GemmParams q = p;
+    q.K = K / 2;                                  // k64_cost counts 64-element (128-byte) steps of bf16
+    int pick = 0;
+    float best = k64_cost(q, FP8_SHAPES[0]);
+    for (int i = 1; i < N_FP8; ++i) {
+        const float c = k64_cost(q, FP8_SHAPES[i]);
+        if (c < best) { best = c; pick = i; }
+    }
+    return FP8_SHAPES[pick].launch(p, s);
 }

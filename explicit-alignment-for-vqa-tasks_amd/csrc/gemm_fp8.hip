@@ -1,0 +1,150 @@
+// fp8 (OCP e4m3) GEMM on the block-scaled matrix instruction (included by gemm.hip behind gemm_k64.hip).
+//
+// BASELINE.json configs[4] ("CLIP ViT-L/14 -> OPT-6.7B fp8 MFMA"): the frozen LM's Linear layers run on
+// v_mfma_scale_f32_16x16x128_f8f6f4 - per MI355X_MICROARCH.md ("Matrix cores") only the block-scaled forms run at twice the bf16
+// rate; the plain _fp8_fp8 MFMAs run at the bf16 rate.  Quantisation scheme (what the parity test's oracle reproduces):
+//   * weights: e4m3 with ONE float scale per tensor, quantised once at load (frozen);
+//   * activations / gradients: e4m3 with one float scale per ROW (token), produced by eavqa_quantize_rows_fp8 right before the
+//     GEMM (dynamic, amax / 448);
+//   * the instruction's own E8M0 block scales are all 1.0 (exponent byte 127): the row and tensor scales are applied to the
+//     fp32 accumulator in the epilogue (row_scale[m] * alpha), then bias / activation / residual as in eavqa_gemm.
+// Structure: the loader / consumer specialised full-line kernel of gemm_k64.hip with byte-addressed operands - a stage row is
+// 128 bytes = 128 fp8 k-values = ONE 16x16x128 MFMA step.  Lane (row r = lane & 15, group g = lane >> 4) of a fragment reads the
+// 16-byte chunks g and g + 4 of its row (the two conflict-free reads of the bf16 kernel's two sub-steps) - i.e. the MFMA's
+// k-group g holds k-values {16g .. 16g+15} and {64+16g .. 64+16g+15} of the stage, the same for A and for B, which permutes the
+// terms of the dot product and nothing else.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+template <int WM, int WN, int MF, int NF, int NST, int LW, bool DB>
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_fp8_k128s_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
+    using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int tm, tn;
+    if (!shaped_tile(gx, gy, tiles_m, tiles_n, tm, tn)) return;
+    const int m0 = tm * G::TBM, n0 = tn * G::TBN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nk = p.K >> 7;                                                // 128 fp8 values per stage row
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wm = wave / WN, wn = wave % WN;
+
+    if (wave >= G::NC) {
+        k64s_loader_role<G>(reinterpret_cast<const char*>(p.A), reinterpret_cast<const char*>(p.B), p.lda, p.ldb, p.M, p.N, m0, n0, nk, smem,
+                            wave - G::NC, lane);
+    } else {
+        const int frow = lane & 15, fk = lane >> 4;
+        const int sw0 = ((fk ^ (frow & 7)) << 4);                           // chunk g; chunk g + 4 is sw0 ^ 64
+        const int a_off = (wm * 16 * MF + frow) * 128;
+        const int b_off = G::AOPER + (wn * 16 * NF + frow) * 128;
+        constexpr int NSET = DB ? 2 : 1;
+        i32x8 fa[NSET][MF], fb[NSET][NF];
+        auto read_frags = [&](int set, const char* st) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(st + a_off + i * 2048 + sw0);
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(st + a_off + i * 2048 + (sw0 ^ 64));
+                fa[set][i] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(st + b_off + j * 2048 + sw0);
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(st + b_off + j * 2048 + (sw0 ^ 64));
+                fb[set][j] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        };
+        auto mfma_all = [&](int set) {
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int j = 0; j < NF; ++j)      // cbsz = blgp = 0: both operands e4m3; block scales 2^0 (E8M0 byte 127 in every lane)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        };
+        __builtin_amdgcn_s_barrier();                                       // tile 0 landed
+        int stage = 0;
+        if (DB) {
+            read_frags(0, smem);
+            for (int t = 0; t < nk; ++t) {
+                const int nstage = (stage + 1 == NST) ? 0 : stage + 1;
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): fragments of tile t complete = done reading stage t
+                if (t + 1 < nk) {
+                    __builtin_amdgcn_s_barrier();                           // tile t+1 landed; the loader may refill stage t
+                    if (t & 1) read_frags(0, smem + nstage * G::STAGE); else read_frags(1, smem + nstage * G::STAGE);
+                }
+                if (t & 1) mfma_all(1); else mfma_all(0);
+                stage = nstage;
+            }
+        } else {
+            for (int t = 0; t < nk; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(0, smem + stage * G::STAGE);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                if (t + 1 < nk) __builtin_amdgcn_s_barrier();
+                mfma_all(0);
+                stage = (stage + 1 == NST) ? 0 : stage + 1;
+            }
+        }
+    }
+    __syncthreads();
+    k64s_store_tile<G, WM, WN, MF, NF>(p, acc, smem, wave, lane, m0, n0);
+}
+
+template <int WM, int WN, int MF, int NF, int NST, int LW, bool DB>
+int launch_fp8(const GemmParams& p, hipStream_t stream) {
+    using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_k128s_kernel<WM, WN, MF, NF, NST, LW, DB>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
+            return EAVQA_E_LAUNCH;
+        configured = true;
+    }
+    const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
+    const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
+    hipLaunchKernelGGL((gemm_fp8_k128s_kernel<WM, WN, MF, NF, NST, LW, DB>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
+                       tiles_m, tiles_n);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+const K64Choice FP8_SHAPES[] = {
+    {128, 80, 1, 1.56f, launch_fp8<4, 1, 2, 5, 4, 2, true>},
+    {256, 128, 1, 1.97f, launch_fp8<4, 2, 4, 4, 3, 4, false>},
+    {256, 160, 1, 1.93f, launch_fp8<4, 2, 4, 5, 3, 4, false>},
+    {128, 128, 1, 1.73f, launch_fp8<2, 2, 4, 4, 3, 2, false>},
+    {128, 256, 1, 1.97f, launch_fp8<2, 4, 4, 4, 3, 4, false>},
+};
+constexpr int N_FP8 = sizeof(FP8_SHAPES) / sizeof(FP8_SHAPES[0]);
+
+// ---- row-wise quantisation: x[r, :] (bf16 or f32) -> e4m3 bytes + scale[r] = amax(|x[r, :]|) / 448 (1 where the row is all zero)
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(int cols, const T* x, int64_t ldx, unsigned char* out, int64_t ld_out,
+                                                                float* row_scale) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const T* xr = x + (int64_t)row * ldx;
+    float amax = 0.f;
+    for (int c = tid * 4; c < cols; c += 1024) {
+        const float4 v = elem<T>::ld4(xr + c);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+    const float inv = 1.f / scale;
+    if (tid == 0) row_scale[row] = scale;
+    unsigned char* o = out + (int64_t)row * ld_out;
+    for (int c = tid * 4; c < cols; c += 1024) {
+        const float4 v = elem<T>::ld4(xr + c);        // second pass: the row is in L2
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.x * inv, v.y * inv, 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(v.z * inv, v.w * inv, pk, true);
+        *reinterpret_cast<int*>(o + c) = pk;
+    }
+}

@@ -243,6 +243,89 @@ template <int WM, int WN, int MF, int NF, int NST_, int LW_> struct K64SGeo {
     static_assert(P_HI * (NST - 1) <= 63 && NST >= 2 && NST <= 4, "vmcnt field");
 };
 
+// The loader role (shared by the bf16 and the fp8 kernels): operands are addressed in BYTES - a stage row is 128 bytes of the
+// operand's K extent, whatever the element type (64 bf16 or 128 fp8).
+template <class G>
+__device__ __forceinline__ void k64s_loader_role(const char* A, const char* B, int64_t lda_bytes, int64_t ldb_bytes, int M, int N, int m0,
+                                                 int n0, int nk, char* smem, int lw, int lane) {
+    constexpr int NST = G::NST;
+    const bool hi = lw < G::N_HI;
+    const char* src[G::P_HI];
+    int dst[G::P_HI];
+#pragma unroll
+    for (int i = 0; i < G::P_HI; ++i) {
+        const int piece = min(lw + G::LW * i, G::PT - 1);                   // (the extra slot of a P_LO loader is never issued)
+        const int row = piece * 8 + (lane >> 3), slot = lane & 7;           // row & 7 == lane >> 3
+        const int kc = (slot ^ (lane >> 3)) * 16;
+        src[i] = row < G::TBM ? A + (int64_t)min(m0 + row, M - 1) * lda_bytes + kc
+                              : B + (int64_t)min(n0 + row - G::TBM, N - 1) * ldb_bytes + kc;
+        dst[i] = piece * 1024;
+    }
+    auto issue = [&](int kt, int stage) {
+        char* st = smem + stage * G::STAGE;
+#pragma unroll
+        for (int i = 0; i < G::P_HI; ++i)
+            if (i < G::P_LO || hi)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (int64_t)kt * 128),
+                                                 (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
+    };
+    auto wait_tiles = [&](int tiles) {                                      // at most `tiles` later tiles of this wave still in flight
+        if (hi) {
+            if (NST >= 4 && tiles >= 3) wait_vm<3 * G::P_HI>();
+            else if (NST >= 3 && tiles >= 2) wait_vm<2 * G::P_HI>();
+            else if (tiles >= 1) wait_vm<G::P_HI>();
+            else wait_vm<0>();
+        } else {
+            if (NST >= 4 && tiles >= 3) wait_vm<3 * G::P_LO>();
+            else if (NST >= 3 && tiles >= 2) wait_vm<2 * G::P_LO>();
+            else if (tiles >= 1) wait_vm<G::P_LO>();
+            else wait_vm<0>();
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NST; ++i)
+        if (i < nk) issue(i, i);
+    wait_tiles(min(nk, NST) - 1);
+    __builtin_amdgcn_s_barrier();                                            // tile 0 visible to the consumers
+    int stage = 0;
+    for (int t = 0; t + 1 < nk; ++t) {
+        wait_tiles(min(nk - 1, t + NST - 1) - (t + 1));                      // tile t+1 landed
+        __builtin_amdgcn_s_barrier();                                        // ... and every consumer is done with stage t
+        if (t + NST < nk) issue(t + NST, stage);
+        stage = (stage + 1 == NST) ? 0 : stage + 1;
+    }
+}
+
+// C tile of the consumer waves -> LDS (the ring) -> shared epilogue, in passes; ALL waves of the workgroup take part.
+template <class G, int WM, int WN, int MF, int NF>
+__device__ __forceinline__ void k64s_store_tile(const GemmParams& p, const f32x4 (&acc)[MF][NF], char* smem, int wave, int lane, int m0, int n0) {
+    const int wm = wave / WN, wn = wave % WN;
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int CH = MF / G::MFC;
+    constexpr int NPASSES = (WM / G::SP) * CH;
+    for (int pass = 0; pass < NPASSES; ++pass) {
+        const int wgrp = pass / CH, chunk = pass % CH;
+        if (wave < G::NC && wm / G::SP == wgrp) {
+            const int r0 = (wm % G::SP) * 16 * G::MFC;
+#pragma unroll
+            for (int i = 0; i < MF; ++i) {
+                if (i / G::MFC != chunk) continue;
+#pragma unroll
+                for (int j = 0; j < NF; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = r0 + (i % G::MFC) * 16 + (lane >> 4) * 4 + r;
+                        const int col = wn * 16 * NF + j * 16 + (lane & 15);
+                        Cs[row * G::PITCH + col] = acc[i][j][r];
+                    }
+            }
+        }
+        __syncthreads();
+        epilogue<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>>(p, Cs, m0 + wgrp * G::SP * 16 * MF + chunk * 16 * G::MFC, n0);
+        if (pass + 1 < NPASSES) __syncthreads();
+    }
+}
+
 template <int WM, int WN, int MF, int NF, int NST, int LW>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
     using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
@@ -261,55 +344,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(Gem
     const int wm = wave / WN, wn = wave % WN;                               // meaningful for consumers (wave < NC)
 
     if (wave >= G::NC) {
-        // ------------------------------------------------------------------ loader
-        const int lw = wave - G::NC;
-        const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
-        const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-        const bool hi = lw < G::N_HI;
-        const bf16_t* src[G::P_HI];
-        int dst[G::P_HI];
-#pragma unroll
-        for (int i = 0; i < G::P_HI; ++i) {
-            const int piece = min(lw + G::LW * i, G::PT - 1);               // (the extra slot of a P_LO loader is never issued)
-            const int row = piece * 8 + (lane >> 3), slot = lane & 7;       // row & 7 == lane >> 3
-            const int kc = (slot ^ (lane >> 3)) * 8;
-            src[i] = row < G::TBM ? A + (int64_t)min(m0 + row, p.M - 1) * p.lda + kc
-                                  : B + (int64_t)min(n0 + row - G::TBM, p.N - 1) * p.ldb + kc;
-            dst[i] = piece * 1024;
-        }
-        auto issue = [&](int kt, int stage) {
-            char* st = smem + stage * G::STAGE;
-#pragma unroll
-            for (int i = 0; i < G::P_HI; ++i)
-                if (i < G::P_LO || hi)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * 64),
-                                                     (__attribute__((address_space(3))) void*)(st + dst[i]), 16, 0, 0);
-        };
-        auto wait_tiles = [&](int tiles) {                                  // at most `tiles` later tiles of this wave still in flight
-            if (hi) {
-                if (NST >= 4 && tiles >= 3) wait_vm<3 * G::P_HI>();
-                else if (NST >= 3 && tiles >= 2) wait_vm<2 * G::P_HI>();
-                else if (tiles >= 1) wait_vm<G::P_HI>();
-                else wait_vm<0>();
-            } else {
-                if (NST >= 4 && tiles >= 3) wait_vm<3 * G::P_LO>();
-                else if (NST >= 3 && tiles >= 2) wait_vm<2 * G::P_LO>();
-                else if (tiles >= 1) wait_vm<G::P_LO>();
-                else wait_vm<0>();
-            }
-        };
-#pragma unroll
-        for (int i = 0; i < NST; ++i)
-            if (i < nk) issue(i, i);
-        wait_tiles(min(nk, NST) - 1);
-        __builtin_amdgcn_s_barrier();                                        // tile 0 visible to the consumers
-        int stage = 0;
-        for (int t = 0; t + 1 < nk; ++t) {
-            wait_tiles(min(nk - 1, t + NST - 1) - (t + 1));                  // tile t+1 landed
-            __builtin_amdgcn_s_barrier();                                    // ... and every consumer is done with stage t
-            if (t + NST < nk) issue(t + NST, stage);
-            stage = (stage + 1 == NST) ? 0 : stage + 1;
-        }
+        k64s_loader_role<G>(reinterpret_cast<const char*>(p.A), reinterpret_cast<const char*>(p.B), p.lda * 2, p.ldb * 2, p.M, p.N, m0, n0, nk,
+                            smem, wave - G::NC, lane);
     } else {
         // ------------------------------------------------------------------ consumer
         const int frow = lane & 15, fk = lane >> 4;
@@ -351,31 +387,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(Gem
         }
     }
     __syncthreads();   // ring free (every DMA was waited for by its loader before the last K-step's barrier)
-
-    float* Cs = reinterpret_cast<float*>(smem);
-    constexpr int CH = MF / G::MFC;
-    constexpr int NPASSES = (WM / G::SP) * CH;
-    for (int pass = 0; pass < NPASSES; ++pass) {
-        const int wgrp = pass / CH, chunk = pass % CH;
-        if (wave < G::NC && wm / G::SP == wgrp) {
-            const int r0 = (wm % G::SP) * 16 * G::MFC;
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                if (i / G::MFC != chunk) continue;
-#pragma unroll
-                for (int j = 0; j < NF; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = r0 + (i % G::MFC) * 16 + (lane >> 4) * 4 + r;
-                        const int col = wn * 16 * NF + j * 16 + (lane & 15);
-                        Cs[row * G::PITCH + col] = acc[i][j][r];
-                    }
-            }
-        }
-        __syncthreads();
-        epilogue<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>>(p, Cs, m0 + wgrp * G::SP * 16 * MF + chunk * 16 * G::MFC, n0);
-        if (pass + 1 < NPASSES) __syncthreads();
-    }
+    k64s_store_tile<G, WM, WN, MF, NF>(p, acc, smem, wave, lane, m0, n0);
 }
 
 template <int WM, int WN, int MF, int NF, int NST, int LW>
@@ -412,17 +424,19 @@ const K64Choice K64_SHAPES[] = {
     {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 2>},          // 11
     {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 4>},          // 12
     {128, 128, 2, 1.1f, launch_k64s<2, 2, 4, 4, 2, 4>},         // 13
-    {256, 128, 1, 1.1f, launch_k64s<4, 2, 4, 4, 3, 4>},         // 14
-    {256, 160, 1, 1.1f, launch_k64s<4, 2, 4, 5, 3, 4>},         // 15
-    {128, 80, 1, 1.1f, launch_k64s<4, 1, 2, 5, 4, 2>},          // 16: four stages (one workgroup per CU)
+    {256, 128, 1, 1.97f, launch_k64s<4, 2, 4, 4, 3, 4>},        // 14
+    {256, 160, 1, 1.93f, launch_k64s<4, 2, 4, 5, 3, 4>},        // 15
+    {128, 80, 1, 1.56f, launch_k64s<4, 1, 2, 5, 4, 2>},         // 16: four stages (one workgroup per CU)
     {128, 96, 1, 1.1f, launch_k64s<4, 1, 2, 6, 3, 2>},          // 17
     {256, 192, 1, 1.1f, launch_k64s<4, 2, 4, 6, 2, 4>},         // 18
     {256, 256, 1, 1.1f, launch_k64s<2, 4, 8, 4, 2, 4>},         // 19
-    {128, 128, 1, 1.1f, launch_k64s<2, 2, 4, 4, 3, 2>},         // 20: three stages
+    {128, 128, 1, 1.73f, launch_k64s<2, 2, 4, 4, 3, 2>},        // 20: three stages
     {256, 128, 1, 1.1f, launch_k64s<2, 2, 8, 4, 3, 4>},         // 21: four fat consumer waves (128 x 64 each)
-    {128, 256, 1, 1.1f, launch_k64s<2, 4, 4, 4, 3, 4>},         // 22
+    {128, 256, 1, 1.97f, launch_k64s<2, 4, 4, 4, 3, 4>},        // 22
 };
 constexpr int N_K64 = sizeof(K64_SHAPES) / sizeof(K64_SHAPES[0]);
-constexpr int N_K64_AUTO = 7;                                      // the dispatcher chooses among the first seven
+// the tiles the dispatcher chooses among (indices into K64_SHAPES): s128x80 (4 stages), s256x128, s256x160, s128x128 (3 stages), s128x256
+constexpr int K64_AUTO[] = {14, 12, 13, 18, 20};
+constexpr int N_K64_AUTO = sizeof(K64_AUTO) / sizeof(K64_AUTO[0]);
 
 

@@ -402,7 +402,7 @@ class _Output:
 
 
 # =========================================================================== models
-def _resolve_lm(model_version: str, dtype, device, seed: int = 2021) -> FrozenCausalLM:
+def _resolve_lm(model_version: str, dtype, device, seed: int = 2021, weight_format: str = "native") -> FrozenCausalLM:
     """``GPT2LMHeadModel.from_pretrained(model_version)`` clipcap.py:252 without network access:
     a local HF directory is loaded; a known architecture name gets seeded random-init weights
     (synthetic benchmarking - say so wherever results are reported)."""
@@ -410,10 +410,10 @@ def _resolve_lm(model_version: str, dtype, device, seed: int = 2021) -> FrozenCa
     for cand in (model_version, os.path.join(root, model_version) if root else ""):
         if cand and os.path.isdir(cand) and os.path.exists(os.path.join(cand, "config.json")):
             cfgd, sd = load_local_hf(cand)
-            return FrozenCausalLM(LMConfig.from_hf_dict(cfgd), sd, dtype, device)
+            return FrozenCausalLM(LMConfig.from_hf_dict(cfgd), sd, dtype, device, weight_format)
     if model_version in KNOWN_CONFIGS:
         cfg = LMConfig.from_hf_dict(KNOWN_CONFIGS[model_version])
-        return FrozenCausalLM(cfg, random_init_state_dict(cfg, seed, device), dtype, device)
+        return FrozenCausalLM(cfg, random_init_state_dict(cfg, seed, device), dtype, device, weight_format)
     raise FileNotFoundError(f"{model_version!r}: not a local HF directory and not a known architecture name; "
                             "no network access is attempted")
 
@@ -423,11 +423,13 @@ class ClipCaptionModel(nn.Module):
 
     def __init__(self, prefix_length: int, clip_length: Optional[int] = None, prefix_size: int = 512, num_layers: int = 8,
                  mapping_type: str = "mlp", model_version: str = "gpt2", *, lm: Optional[FrozenCausalLM] = None,
-                 dtype: torch.dtype = torch.bfloat16, device="cuda"):
+                 dtype: torch.dtype = torch.bfloat16, device="cuda", lm_weight_format: str = "native"):
+        """``lm_weight_format="fp8"`` (an addition to the reference's ``model_args``, BASELINE configs[4]): hold the frozen LM's
+        Linear weights in e4m3 and run them on the block-scaled MFMA (models/lm.py ``Fp8Weight``)."""
         super().__init__()
         self.prefix_length = prefix_length
         self.dtype, self.device_ = dtype, torch.device(device)
-        self.gpt = lm if lm is not None else _resolve_lm(model_version, dtype, device)
+        self.gpt = lm if lm is not None else _resolve_lm(model_version, dtype, device, weight_format=lm_weight_format)
         self.gpt_embedding_size = self.gpt.cfg.n_embd
         E = self.gpt_embedding_size
         self.mapping_type = mapping_type
@@ -531,7 +533,7 @@ class ClipCaptionModel(nn.Module):
     def generate_fewshot(self, question_tokens: Tensor, prefix: Tensor, question_mask: Optional[Tensor] = None,
                          num_shots: Optional[int] = None, special_token_id: int = 32099, max_length: Optional[int] = 10,
                          pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None,
-                         use_cache: bool = True, output_scores: bool = False):
+                         use_cache: bool = True, output_scores: bool = False, marks: Optional[list] = None):
         """Few-shot prompt path: the causal-LM counterpart of ``VCT0Model.generate`` with
         ``insert_prefix_into_input`` (src/models/vct0.py:446-464,494-533).  ``prefix``: [B, n_img, D] (or
         [B, n_img, 1, D]) CLIP embeddings; the n-th sentinel token (ids ``special_token_id - i``) of each row
@@ -560,7 +562,7 @@ class ClipCaptionModel(nn.Module):
         if not bool((status == n_img).all().item()):
             raise ValueError("every row must hold exactly one sentinel token per image")   # vct0.py:512 .view fails
         S0 = T + (L - 1) * n_img
-        return greedy_decode(lm, rows, src, mask, pos, B, S0, max_length, pad_token_id, eos_token_id, use_cache, output_scores)
+        return greedy_decode(lm, rows, src, mask, pos, B, S0, max_length, pad_token_id, eos_token_id, use_cache, output_scores, marks)
 
 
 class ClipCaptionPrefix(ClipCaptionModel):

@@ -23,11 +23,13 @@ Tensor = torch.Tensor
 
 def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Tensor, pos: Tensor, B: int, S0: int,
                   max_length: int, pad_token_id: Optional[int], eos_token_id: Optional[int], use_cache: bool = True,
-                  output_scores: bool = False):
+                  output_scores: bool = False, marks: Optional[list] = None):
     """``src/mask/pos``: int32 [B, S0 + max_length] for the whole horizon (appended positions have mask 1;
     their ``src`` entries are filled in as tokens are produced).  ``output_scores``: also return the float32
     [B, produced] log-probabilities of the raw greedy tokens (what HF's ``output_scores=True`` yields after
-    ``log(softmax)``, few_shot_vqa_executor.py:301-314)."""
+    ``log(softmax)``, few_shot_vqa_executor.py:301-314).  ``marks`` (bench instrumentation): a list that receives
+    ``("prefill", event)`` and ``("decode", event)`` - HIP events recorded on the launch stream behind the prefill and behind the
+    last decode step."""
     dev = lm.device
     S_max = S0 + max_length
     tokens = torch.zeros((B, max_length), dtype=torch.int64, device=dev)
@@ -38,6 +40,7 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
     if use_cache:
         cache = _KVCache(lm, B, S_max, B * S0)
         logits = _prefill(lm, cache, prefix_rows, src[:, :S0].contiguous(), pos[:, :S0].contiguous(), mask, B, S0, S_max)
+    _mark(marks, "prefill")
     for t in range(max_length):
         if not use_cache:
             S = S0 + t
@@ -51,16 +54,27 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
             break                                              # clipcap.py:463
         if t + 1 < max_length and use_cache:
             logits = _decode_step(lm, cache, raw, pos[:, S0 + t].contiguous(), mask, B, S0 + t, S_max)
+    _mark(marks, "decode")
     ids = tokens[:, :produced].cpu().numpy().astype(int).tolist()   # clipcap.py:469
     if output_scores:
         return ids, logp[:produced].t().contiguous().cpu()
     return ids
 
 
+def _mark(marks: Optional[list], name: str) -> None:
+    if marks is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        marks.append((name, ev))
+
+
 class _KVCache:
     """Per-layer K/V ``[B, S_max, E]`` plus the host-side layer table and scratch for ``eavqa_lm_block_forward``."""
 
     def __init__(self, lm: FrozenCausalLM, B: int, S_max: int, max_rows: int):
+        if getattr(lm, "weight_format", "native") != "native":
+            raise NotImplementedError("cached generation streams bf16 / fp32 weights (eavqa_lm_block_forward); an fp8 LM generates with "
+                                      "use_cache=False (the reference's own full re-forward, src/models/clipcap.py:414-419)")
         E, F = lm.cfg.n_embd, lm.cfg.ffn
         self.k = [torch.empty((B * S_max, E), device=lm.device, dtype=lm.dtype) for _ in lm.layers]
         self.v = [torch.empty((B * S_max, E), device=lm.device, dtype=lm.dtype) for _ in lm.layers]

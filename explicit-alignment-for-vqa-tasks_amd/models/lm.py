@@ -139,6 +139,39 @@ def load_local_hf(path: str):
     raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {path}")
 
 
+class Fp8Weight:
+    """A frozen Linear weight ``[N, K]`` held as OCP e4m3 bytes with ONE float scale (``w ~ scale * e4m3``): BASELINE
+    configs[4].  ``t()`` is the transposed copy for the dgrad GEMM - the same bytes transposed, the same scale."""
+
+    __slots__ = ("q", "scale", "shape")
+
+    def __init__(self, q: Tensor, scale: float):
+        self.q, self.scale, self.shape = q, float(scale), tuple(q.shape)
+
+    @staticmethod
+    def quantize(w: Tensor, device) -> "Fp8Weight":
+        w = w.to(device=device, dtype=torch.float32)
+        amax = float(w.abs().max().item())
+        scale = amax / 448.0 if amax > 0 else 1.0
+        q = (w / scale).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()      # load-time cast (torch), not on the hot path
+        return Fp8Weight(q, scale)
+
+    def t(self) -> "Fp8Weight":
+        return Fp8Weight(self.q.T.contiguous(), self.scale)
+
+    def dequantize(self) -> Tensor:
+        return self.q.view(torch.float8_e4m3fn).float() * self.scale
+
+
+def linear(a: Tensor, w, **kw) -> Tensor:
+    """``epilogue(a @ w^T)``: the bf16 / fp32 MFMA GEMM, or - for an :class:`Fp8Weight` - row-wise e4m3 quantisation of ``a``
+    followed by the block-scaled fp8 GEMM (eavqa_quantize_rows_fp8 + eavqa_gemm_fp8)."""
+    if isinstance(w, Fp8Weight):
+        aq, a_scale = ops.quantize_rows_fp8(a)
+        return ops.gemm_fp8(aq, a_scale, w.q, w.scale, **kw)
+    return ops.gemm(a, w, **kw)
+
+
 class _Layer:
     __slots__ = ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
                  "w_qkv_t", "w_o_t", "w_fc1_t", "w_fc2_t")
@@ -147,10 +180,19 @@ class _Layer:
 class FrozenCausalLM:
     """Weights of a frozen GPT-2 / OPT decoder pre-packed for the HIP kernels + forward / dgrad drivers."""
 
-    def __init__(self, cfg: LMConfig, state_dict: Dict[str, Tensor], dtype: torch.dtype = torch.bfloat16, device="cuda"):
+    def __init__(self, cfg: LMConfig, state_dict: Dict[str, Tensor], dtype: torch.dtype = torch.bfloat16, device="cuda",
+                 weight_format: str = "native"):
+        """``weight_format="fp8"`` (with ``dtype=torch.bfloat16``): the Linear weights of every layer and the lm_head are held
+        in e4m3 with per-tensor scales and multiplied on the block-scaled MFMA; activations stay bf16 in HBM and are quantised
+        row-wise right in front of each GEMM; LayerNorm, attention, the residual stream (fp32) and the loss are unchanged."""
         self.cfg = cfg
         self.dtype = dtype
         self.device = torch.device(device)
+        if weight_format not in ("native", "fp8"):
+            raise ValueError("weight_format must be 'native' or 'fp8'")
+        if weight_format == "fp8" and (dtype != torch.bfloat16 or cfg.n_embd % 128 or cfg.ffn % 128):
+            raise ValueError("fp8 weights need bfloat16 activations and n_embd / ffn multiples of 128")
+        self.weight_format = weight_format
         self._pack(state_dict)
         self._bwd_ready = False
 
@@ -202,6 +244,12 @@ class FrozenCausalLM:
         # lm_head is tied to wte in both families; an untied head is kept separately
         self.head = self.wte if head is None or head.shape == self.wte.shape and _same(head, self.wte) else self._T(head)
         self.head_t = None
+        self.head_q = None
+        if self.weight_format == "fp8":
+            for L in self.layers:
+                for name in ("w_qkv", "w_o", "w_fc1", "w_fc2"):
+                    setattr(L, name, Fp8Weight.quantize(getattr(L, name), self.device))
+            self.head_q = Fp8Weight.quantize(self.head, self.device)      # the bf16 wte stays for the embedding gather
 
     @property
     def vocab(self) -> int:
@@ -209,20 +257,27 @@ class FrozenCausalLM:
 
     @property
     def vpad(self) -> int:
-        return (self.vocab + 63) // 64 * 64   # K of the lm_head dgrad GEMM: a multiple of the fast path's BK
+        q = 128 if self.weight_format == "fp8" else 64
+        return (self.vocab + q - 1) // q * q   # K of the lm_head dgrad GEMM: a multiple of the kernels' K-step
 
     def _prepare_backward(self) -> None:
         """Transposed weight copies for the dgrad GEMMs (made once, on the first training step)."""
         if self._bwd_ready:
             return
+        tr = (lambda w: w.t()) if self.weight_format == "fp8" else (lambda w: w.T.contiguous())
         for L in self.layers:
-            L.w_qkv_t = L.w_qkv.T.contiguous()
-            L.w_o_t = L.w_o.T.contiguous()
-            L.w_fc1_t = L.w_fc1.T.contiguous()
-            L.w_fc2_t = L.w_fc2.T.contiguous()
+            L.w_qkv_t = tr(L.w_qkv)
+            L.w_o_t = tr(L.w_o)
+            L.w_fc1_t = tr(L.w_fc1)
+            L.w_fc2_t = tr(L.w_fc2)
         V, E = self.head.shape
-        self.head_t = torch.zeros((E, self.vpad), device=self.device, dtype=self.dtype)
-        self.head_t[:, :V] = self.head.T
+        if self.weight_format == "fp8":
+            qt = torch.zeros((E, self.vpad), device=self.device, dtype=torch.uint8)      # e4m3 zero = byte 0
+            qt[:, :V] = self.head_q.q.T
+            self.head_t = Fp8Weight(qt, self.head_q.scale)
+        else:
+            self.head_t = torch.zeros((E, self.vpad), device=self.device, dtype=self.dtype)
+            self.head_t[:, :V] = self.head.T
         self._bwd_ready = True
 
     def resize_token_embeddings(self, n: int) -> None:
@@ -248,6 +303,8 @@ class FrozenCausalLM:
             self.head = h
         self.cfg.vocab = n
         self._bwd_ready = False
+        if self.weight_format == "fp8":
+            self.head_q = Fp8Weight.quantize(self.head, self.device)
 
     def load_token_embeddings(self, weight: Tensor) -> None:
         """Replace the token embedding matrix (and the tied head) by ``weight`` [vocab, E] - e.g. the rows a reference
@@ -259,6 +316,8 @@ class FrozenCausalLM:
         if tied:
             self.head = self.wte
         self._bwd_ready = False
+        if self.weight_format == "fp8":
+            self.head_q = Fp8Weight.quantize(self.head, self.device)
 
     # ---------------------------------------------------------------- forward
     def forward(self, prefix_rows: Optional[Tensor], src: Tensor, pos: Tensor, mask: Tensor, B: int, S: int, *,
@@ -298,22 +357,22 @@ class FrozenCausalLM:
                 a, mean1, rstd1 = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T, save_stats=True)
             else:
                 a = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T)
-            qkv = ops.gemm(a, L.w_qkv, bias=L.b_qkv)
+            qkv = linear(a, L.w_qkv, bias=L.b_qkv)
             q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
             if save:
                 ctx, lse = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=attn_mask, causal=True, scale=scale,
                                              save_lse=True, cu_seqlens=cu)
             else:
                 ctx = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=attn_mask, causal=True, scale=scale, cu_seqlens=cu)
-            x1 = ops.gemm(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True)
+            x1 = linear(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True)
             if save:
                 a2, mean2, rstd2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T, save_stats=True)
                 u = torch.empty((M, c.ffn), device=self.device, dtype=T)
-                f = ops.gemm(a2, L.w_fc1, bias=L.b_fc1, act=c.act, aux_out=u)
+                f = linear(a2, L.w_fc1, bias=L.b_fc1, act=c.act, aux_out=u)
             else:
                 a2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T)
-                f = ops.gemm(a2, L.w_fc1, bias=L.b_fc1, act=c.act)
-            x2 = ops.gemm(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True)
+                f = linear(a2, L.w_fc1, bias=L.b_fc1, act=c.act)
+            x2 = linear(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True)
             if save:
                 tape.append((x, mean1, rstd1, qkv, ctx, lse, x1, mean2, rstd2, u))
             x = x2
@@ -352,6 +411,9 @@ class FrozenCausalLM:
     def _head(self, hf: Tensor) -> Tensor:
         """lm_head GEMM into a [rows, vpad] fp32 buffer (pad columns are never read)."""
         lg = torch.empty((hf.shape[0], self.vpad), device=self.device, dtype=torch.float32)
+        if self.head_q is not None:
+            linear(hf, self.head_q, out=lg[:, :self.vocab])
+            return lg
         if hf.shape[0] <= 64 and hf.dtype == torch.bfloat16 and self.vocab % 4 == 0 and self.cfg.n_embd % 32 == 0:
             # a decode step: stream the [V, E] head once with K split over workgroups (csrc/decode.hip)
             ops.splitk_finish(ops.gemm_splitk(hf, self.head[:self.vocab]), [lg[:, :self.vocab]])
@@ -373,21 +435,21 @@ class FrozenCausalLM:
         # the residual-stream gradient lives in fp32 (dx); each LayerNorm backward also emits the copy in the
         # compute dtype that the next dgrad GEMM consumes as its A operand (no separate cast pass)
         dlog = ops.ce_bwd(tape["logits"], tape["labels"], self.vocab, tape["row_lse"], tape["count"], gloss, T, self.vpad)
-        dhf = ops.gemm(dlog, self.head_t)                                   # [M,E] (or [n_scored,E])
+        dhf = linear(dlog, self.head_t)                                   # [M,E] (or [n_scored,E])
         if tape.get("sel") is not None:
             dhf = ops.scatter_rows(dhf, tape["sel"], M)                      # rows without a label get no gradient here
         dxT = torch.empty((M, E), device=self.device, dtype=T) if lowp else None
         dx = ops.layernorm_bwd(tape["x_last"], dhf, self.lnf_g, tape["meanf"], tape["rstdf"], lowp_out=dxT)
         for L, (x, mean1, rstd1, qkv, ctx, lse, x1, mean2, rstd2, u) in zip(reversed(self.layers), reversed(tape["layers"])):
-            du = ops.gemm(dxT if lowp else dx, L.w_fc2_t, act=c.act, aux_in=u)   # (dx W2) * act'(u)   [M,F]
-            da2 = ops.gemm(du, L.w_fc1_t)                                    # [M,E]
+            du = linear(dxT if lowp else dx, L.w_fc2_t, act=c.act, aux_in=u)   # (dx W2) * act'(u)   [M,F]
+            da2 = linear(du, L.w_fc1_t)                                    # [M,E]
             dx1 = ops.layernorm_bwd(x1, da2, L.ln2_g, mean2, rstd2, dres=dx, out=dx, lowp_out=dxT)
-            dctx = ops.gemm(dxT if lowp else dx1, L.w_o_t)                   # [M,E]
+            dctx = linear(dxT if lowp else dx1, L.w_o_t)                   # [M,E]
             dqkv = torch.empty_like(qkv)
             q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
             ops.attention_bwd(q, k, v, ctx, dctx, lse, B, H, S, S, hd, key_mask=mask, causal=True, scale=scale,
                               dq=dqkv[:, :E], dk=dqkv[:, E:2 * E], dv=dqkv[:, 2 * E:], cu_seqlens=cu)
-            da = ops.gemm(dqkv, L.w_qkv_t)                                   # [M,E]
+            da = linear(dqkv, L.w_qkv_t)                                   # [M,E]
             dx = ops.layernorm_bwd(x, da, L.ln1_g, mean1, rstd1, dres=dx1, out=dx1, lowp_out=dxT)
         return ops.embed_assemble_bwd(tape["src"], dx, n_prefix_rows, T)
 

@@ -83,6 +83,35 @@ def gemm(a: Tensor, b: Tensor, *, a_kc: bool = True, b_kc: bool = True, bias: Op
     return out
 
 
+def quantize_rows_fp8(x: Tensor):
+    """Rows of ``x`` (bf16 / fp32 [rows, cols]) -> (e4m3 bytes as uint8 [rows, cols], float32 row scales [rows])."""
+    _dev(x)
+    rows, cols = x.shape
+    q = torch.empty((rows, cols), device=x.device, dtype=torch.uint8)
+    sc = torch.empty(rows, device=x.device, dtype=torch.float32)
+    call("eavqa_quantize_rows_fp8", dtype_id(x.dtype), rows, cols, _p(x), _ld(x), _p(q), _ld(q), _p(sc), _stream())
+    return q, sc
+
+
+def gemm_fp8(a_q: Tensor, a_scale: Tensor, b_q: Tensor, b_scale: float, *, bias: Optional[Tensor] = None, act: str = "none",
+             aux_in: Optional[Tensor] = None, aux_out: Optional[Tensor] = None, residual: Optional[Tensor] = None,
+             out: Optional[Tensor] = None, out_f32: bool = False, alpha: float = 1.0, tile: int = 0) -> Tensor:
+    """``C = epilogue(alpha * b_scale * a_scale[m] * A_q @ B_q^T)`` on e4m3 operands (uint8 storage) - see eavqa_gemm_fp8.
+    Outputs / aux are bfloat16 (or float32 ``out``)."""
+    _dev(a_q)
+    M, K = a_q.shape
+    N = b_q.shape[0]
+    if b_q.shape[1] != K:
+        raise _lib.EavqaError(f"gemm_fp8 inner dims differ: {K} vs {b_q.shape[1]}")
+    if out is None:
+        out = torch.empty((M, N), device=a_q.device, dtype=torch.float32 if out_f32 else torch.bfloat16)
+    aux = aux_in if aux_in is not None else aux_out
+    call("eavqa_gemm_fp8", M, N, K, _p(a_q), _ld(a_q), _p(a_scale), _p(b_q), _ld(b_q), float(b_scale), _p(out), _ld(out),
+         int(out.dtype == torch.float32), float(alpha), _p(bias), ACT[act], _p(aux_in), _p(aux_out), _ld(aux) if aux is not None else 0,
+         _p(residual), _ld(residual) if residual is not None else 0, _stream(), int(tile))
+    return out
+
+
 def layernorm_fwd(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float, out_dtype: torch.dtype,
                   save_stats: bool = False, out: Optional[Tensor] = None):
     """Rows of ``x`` ([rows, cols], float32 or ``out_dtype``) -> ``y`` in ``out_dtype`` (+ mean, rstd)."""

@@ -291,6 +291,20 @@ int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int
 int eavqa_l2_normalize_rows(int rows, int cols, float* x, int64_t ld, void* stream);
 int eavqa_topk_rows(int rows, int cols, const float* scores, int64_t ld, int k, float* out_val, int64_t* out_idx, void* stream);
 
+/* ---- fp8 path (BASELINE configs[4]: the frozen LM's Linear layers in OCP e4m3 on the block-scaled MFMA) -----------------------
+ * eavqa_quantize_rows_fp8: x[r, :] (`dtype`: float32 or bfloat16) -> out[r, :] one e4m3 byte per element, row_scale[r] =
+ * max|x[r, :]| / 448 (1 for an all-zero row), out = round-to-nearest-even(x / row_scale) (v_cvt_pk_fp8_f32).  cols % 4 == 0.
+ * eavqa_gemm_fp8: C[M,N] = epilogue(alpha * b_scale * a_row_scale[m] * sum_k A(m,k) * B(n,k)), A [M,K] and B [N,K] e4m3 bytes,
+ * k contiguous, K % 128 == 0, lda / ldb % 16 == 0; fp32 accumulation in v_mfma_scale_f32_16x16x128_f8f6f4 with unit block
+ * scales; epilogue (bias, act, aux_in / aux_out, residual, C) exactly as eavqa_gemm with `dtype` = bfloat16.  Replaces the
+ * nn.Linear matmuls of HF:models/opt/modeling_opt.py:137-181,228-248 (forward) and their dgrad when the LM is held in fp8.
+ * `tile`: 0 = choose by shape; 1.. force a tile (tests / tools). */
+int eavqa_quantize_rows_fp8(int dtype, int rows, int cols, const void* x, int64_t ldx, void* out, int64_t ld_out,
+                            float* row_scale, void* stream);
+int eavqa_gemm_fp8(int M, int N, int K, const void* A, int64_t lda, const float* a_row_scale, const void* B, int64_t ldb,
+                   float b_scale, void* C, int64_t ldc, int out_f32, float alpha, const float* bias, int act,
+                   const void* aux_in, void* aux_out, int64_t ld_aux, const float* residual, int64_t ldr, void* stream, int tile);
+
 /* float32 -> `dtype` elementwise copy with row strides (casts the residual stream / pooled rows). */
 int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream);
 

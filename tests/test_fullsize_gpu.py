@@ -62,12 +62,15 @@ def _train_case(vit_name, lm_name, B, seed):
     return cfg, sd, b
 
 
-def _oracle_train(cfg, sd, vcfg, vsd, mapper_sd, b, L):
-    mapper = {k: v.clone().requires_grad_(True) for k, v in mapper_sd.items()}
-    with torch.no_grad():
-        emb = oracle.clip_vit_encode(vsd, _vit_oracle_cfg(vcfg), b["pixel_values"])
+def _oracle_train(cfg, sd, vcfg, vsd, mapper_sd, b, L, dtype=torch.float32, emb=None):
+    mapper = {k: v.to(dtype).clone().requires_grad_(True) for k, v in mapper_sd.items()}
+    if emb is None:
+        with torch.no_grad():
+            emb = oracle.clip_vit_encode(vsd, _vit_oracle_cfg(vcfg), b["pixel_values"])
+    if dtype != torch.float32:
+        sd = {k: v.to(dtype) for k, v in sd.items()}
     ocfg = dict(arch=cfg.arch, n_layer=cfg.n_layer, n_head=cfg.n_head, act=cfg.act)
-    loss, logits = oracle.clipcap_forward(sd, ocfg, mapper, dict(prefix_length=L, mapping_type="mlp"), b["input_ids"], emb,
+    loss, logits = oracle.clipcap_forward(sd, ocfg, mapper, dict(prefix_length=L, mapping_type="mlp"), b["input_ids"], emb.to(dtype),
                                           b["attention_mask"], b["labels"])
     loss.backward()
     return emb, loss.detach(), logits.detach(), {k: v.grad for k, v in mapper.items()}
@@ -121,7 +124,22 @@ def test_training_step_real_size_matches_oracle(name, vit_name, lm_name, B):
         return e
 
     e = report("fp32", f32)
-    assert e["emb"] <= 1e-3 and e["logits"] <= 1e-3 and e["loss"] <= 1e-4 and e["grad"] <= 1e-3, e
+    assert e["emb"] <= 1e-3 and e["logits"] <= 1e-3 and e["loss"] <= 1e-4, e
+    grad_tol = 1e-3
+    if cfg.act == "relu":
+        # ReLU's derivative is discontinuous: a pre-activation within rounding distance of 0 takes different sides under different
+        # fp32 summation orders, and each such flip changes one hidden unit's whole gradient term.  Measured on MI355X (tools/
+        # diag_bwd.py): against the SAME oracle in float64 this path is off by 6e-6 .. 2.5e-3 and the fp32 CPU oracle by 1.1e-3 ..
+        # 2.2e-3 (smooth activations: both <= 8e-6).  So the judge is the float64 gradient, and the bound is what the fp32 oracle
+        # itself needs, doubled.
+        _, _, _, g64 = _oracle_train(cfg, sd, vcfg, vsd, f32["mapper"], b, L, dtype=torch.float64, emb=emb)
+        rel = lambda got: max((got[k].double() - g).abs().max().item() / max(g.abs().max().item(), 1e-12) for k, g in g64.items())
+        e_hip, e_o32 = rel(f32["grads"]), rel(grads)
+        print(f"[{name} fp32] mapper gradient vs float64 oracle: this path {e_hip:.2e}, fp32 CPU oracle {e_o32:.2e}")
+        grad_tol = max(1e-3, 2.0 * e_o32)
+        assert e_hip <= grad_tol, (e_hip, e_o32)
+    else:
+        assert e["grad"] <= grad_tol, e
     bf = _hip_train(cfg, sd, vit_name, vsd, torch.bfloat16, b, L, mapper_sd=f32["mapper"])
     e = report("bf16", bf)
     for k, tol in BF16_TOL.items():

@@ -33,17 +33,34 @@ def run(arch, E, H, F, act, n_layer=1, V=512, B=2, T=32, L=10, D=64, dtype=torch
     ocfg = dict(arch=arch, n_layer=n_layer, n_head=H, act=act)
     loss, logits = oracle.clipcap_forward(sd, ocfg, mapper, dict(prefix_length=L, mapping_type="mlp"), ids, prefix, mask, labels)
     loss.backward()
-    errs = []
+    # the same oracle in float64: how far are the two fp32 implementations from the exact gradient?
+    sd64 = {k: v.double() for k, v in sd.items()}
+    m64 = {k: v.detach().double().clone().requires_grad_(True) for k, v in mapper.items()}
+    l64, _ = oracle.clipcap_forward(sd64, ocfg, m64, dict(prefix_length=L, mapping_type="mlp"), ids, prefix.double(), mask, labels)
+    l64.backward()
+    errs, errs_hip64, errs_o64 = [], [], []
     for k, p in model.clip_project.named_parameters():
         w = mapper[k].grad
         errs.append((p.grad.float().cpu() - w).abs().max().item() / w.abs().max().item())
+        e = m64[k].grad
+        errs_hip64.append((p.grad.double().cpu() - e).abs().max().item() / e.abs().max().item())
+        errs_o64.append((w.double() - e).abs().max().item() / e.abs().max().item())
+    print(f"      vs float64 oracle: HIP {max(errs_hip64):.3e}   fp32 oracle {max(errs_o64):.3e}")
     att = torch.cat([torch.ones(B, L, dtype=torch.bool), mask.bool()], 1)
     print(f"{arch:5s} E={E:5d} H={H:3d} hd={E//H:4d} F={F:6d} act={act:9s} layers={n_layer} perturb={int(perturb)}: |d loss| {abs(out.loss.item()-loss.item()):.2e} "
           f"max|d logits| {(out.logits.float().cpu()-logits.detach())[att].abs().max().item():.2e}  max rel d grad {max(errs):.3e}", flush=True)
 
-for args in [("opt", 2048, 32, 8192, "relu"), ("opt", 2048, 16, 8192, "relu"), ("opt", 2048, 32, 8192, "gelu_new"), ("gpt2", 2048, 32, 8192, "gelu_new"),
-             ("gpt2", 2048, 32, 8192, "relu"), ("opt", 1280, 20, 5120, "relu"), ("opt", 2048, 32, 2048, "relu"), ("opt", 512, 8, 8192, "relu"),
-             ("opt", 2560, 32, 10240, "relu"), ("opt", 4096, 32, 16384, "relu")]:
-    run(*args)
-run("opt", 2048, 32, 8192, "relu", perturb=False)
-run("opt", 2048, 32, 8192, "relu", n_layer=4)
+import sys
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+if which in ("all", "hd80"):
+    run("opt", 640, 8, 2560, "relu")                  # hd 80, small
+    run("gpt2", 640, 8, 2560, "gelu_new")
+    run("opt", 768, 8, 3072, "relu")                  # hd 96
+    run("opt", 640, 8, 2560, "relu", dtype=torch.bfloat16)
+    run("opt", 640, 4, 2560, "relu")                  # hd 160
+if which in ("all", "cfg3"):
+    run("opt", 2048, 32, 8192, "relu", n_layer=4, V=50272, D=768)
+    run("opt", 2048, 32, 8192, "relu", n_layer=4, V=50272, D=768, B=2, T=32, L=10)
+    run("opt", 2048, 32, 8192, "relu", n_layer=24, V=512, D=64)
+    run("opt", 2048, 32, 8192, "relu", n_layer=24, V=50272, D=768)
+    run("gpt2", 2048, 32, 8192, "gelu_new", n_layer=24, V=50272, D=768)
