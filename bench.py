@@ -37,21 +37,30 @@ WORKLOADS = {
                  desc="CLIP ViT-B/32 -> GPT-2-small, MLP mapper, batch 4 (the reference's CPU-runnable case)"),
     "cfg3": dict(vit="ViT-L/14", lm="facebook/opt-1.3b", mapping_type="mlp", prefix_length=10, batch=64, text_len=32,
                  desc="CLIP ViT-L/14 -> OPT-1.3B, MLP mapper, prefix 10"),
+    # BASELINE.json configs[4]: fp8 frozen LM, 32-token prefix.  Mapper: the reference's TransformerMapper (1.17 B parameters at
+    # E = 4096, src/models/clipcap.py:265-271) - its MLP formula (:256-262) gives 768 -> 65 536 -> 131 072 = 8.64 B parameters, larger
+    # than the LM; `--mapping-type mlp` runs that variant (155 GB of mapper state on one GPU).
+    "cfg5": dict(vit="ViT-L/14", lm="facebook/opt-6.7b", mapping_type="transformer", prefix_length=32, clip_length=32, batch=32, text_len=32,
+                 desc="CLIP ViT-L/14 -> OPT-6.7B (fp8 e4m3 weights on the block-scaled MFMA with --dtype fp8), transformer mapper (8 layers), prefix 32"),
 }
 
 # algorithmic FLOPs per sample: ViT fwd + 3 x mapper + 2 x LM fwd, 2*params*tokens for
 # GEMMs + 4*S^2*E per layer for attention
-def flops_per_sample(vit_cfg, lm_cfg, L, S, D):
+def flops_per_sample(vit_cfg, lm_cfg, L, S, D, mapping_type="mlp", clip_length=10, num_layers=8):
     W, N = vit_cfg.width, vit_cfg.n_patch + 1
     vit = vit_cfg.n_layer * (2 * N * (4 * W * W + 2 * W * vit_cfg.mlp) + 4 * N * N * W) + 2 * vit_cfg.n_patch * 3 * vit_cfg.patch ** 2 * W + 2 * W * vit_cfg.proj
     E, F, V = lm_cfg.n_embd, lm_cfg.ffn, lm_cfg.vocab
     lm = lm_cfg.n_layer * (2 * S * (4 * E * E + 2 * E * F) + 4 * S * S * E) + 2 * S * E * V
-    H = E * L // 2
-    mapper = 2 * (D * H + H * E * L)
+    if mapping_type == "transformer":
+        seq = clip_length + L
+        mapper = 2 * D * clip_length * E + num_layers * (2 * seq * 8 * E * E + 4 * seq * seq * E)
+    else:
+        H = E * L // 2
+        mapper = 2 * (D * H + H * E * L)
     return vit + 3 * mapper + 2 * lm
 
 
-def build_workload(name, dtype, device, rank, mapping_type=None):
+def build_workload(name, dtype, device, rank, mapping_type=None, weight_format="native"):
     from eavqa_amd.data.synthetic import cc_batch
     from eavqa_amd.models.clip_vit import KNOWN_VITS, ClipVisionEncoder, random_init_vit_state_dict
     from eavqa_amd.models.clipcap import ClipCaptionPrefix
@@ -64,7 +73,7 @@ def build_workload(name, dtype, device, rank, mapping_type=None):
     vcfg = KNOWN_VITS[w["vit"]]
     lcfg = LMConfig.from_hf_dict(KNOWN_CONFIGS[w["lm"]])
     vit = ClipVisionEncoder(vcfg, random_init_vit_state_dict(vcfg, 2021, device), dtype, device)
-    lm = FrozenCausalLM(lcfg, random_init_state_dict(lcfg, 2021, device), dtype, device)
+    lm = FrozenCausalLM(lcfg, random_init_state_dict(lcfg, 2021, device), dtype, device, weight_format=weight_format)
     torch.manual_seed(2021)   # mapper init = nn.Linear default under the reference seed
     model = ClipCaptionPrefix(prefix_length=w["prefix_length"], clip_length=w.get("clip_length", w["prefix_length"]), prefix_size=vcfg.proj,
                               mapping_type=w["mapping_type"], lm=lm, dtype=dtype, device=device).train()
@@ -290,7 +299,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8: bf16 activations, the frozen LM's Linear weights in e4m3 on the block-scaled MFMA (cfg5)")
     ap.add_argument("--cpu-baseline-samples", type=int, default=64, help="0 disables the CPU baseline leg (default: one whole step of the workload, ~10 s)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dp-exchange", choices=["auto", "factors", "allreduce", "sharded"], default="auto",
@@ -316,10 +326,11 @@ def main():
     device = f"cuda:{dev_index}"
     if _lib.load().eavqa_check_device() != 0:
         raise SystemExit("device is not gfx950")
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    weight_format = "fp8" if args.dtype == "fp8" else "native"
 
     log(f"building workload {args.workload} ({args.dtype}) on {device}")
-    w, vcfg, lcfg, vit, model, opt, batch, pad = build_workload(args.workload, dtype, device, rank, args.mapping_type)
+    w, vcfg, lcfg, vit, model, opt, batch, pad = build_workload(args.workload, dtype, device, rank, args.mapping_type, weight_format)
     torch.cuda.synchronize()
     log("workload built")
     # N > 1: which exchange carries the mapper gradient
@@ -375,7 +386,7 @@ def main():
 
     roof = None
     if not args.no_roofline:
-        roof = gemm_roofline(stepper, ops, args.workload)      # every rank runs it (the step contains the all-reduce); rank 0 reports
+        roof = gemm_roofline(stepper, ops, args.workload, args.dtype)      # every rank runs it (the step contains the all-reduce); rank 0 reports
         if rank == 0:
             log(f"roofline pass done: {roof}")
     extra = None
@@ -395,7 +406,7 @@ def main():
         log(f"cpu baseline done: {cpu}")
 
     if rank == 0:
-        fps = flops_per_sample(vcfg, lcfg, w["prefix_length"], S, vcfg.proj)
+        fps = flops_per_sample(vcfg, lcfg, w["prefix_length"], S, vcfg.proj, w["mapping_type"], w.get("clip_length", w["prefix_length"]))
         line = {
             "metric": "mapper_train_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -417,27 +428,58 @@ def main():
         dist.destroy_process_group()
 
 
-def gemm_roofline(stepper, ops, workload="cfg2"):
+def gemm_source_digest():
+    """sha256 (first 12 hex digits) over the GEMM kernel sources: stamps the PMC traffic file, so that a traffic figure measured
+    on other kernels is never paired with this run's timings."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("gemm.hip", "gemm_k64.hip", "gemm_fp8.hip", "common.h"):
+        with open(os.path.join(ROOT, "explicit-alignment-for-vqa-tasks_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def gemm_roofline(stepper, ops, workload="cfg2", dtype_name="bf16"):
     """HIP events (torch.cuda.Event records on the current stream = the stream eavqa_gemm launches on) around every
-    GEMM launch of one extra step: achieved = algorithmic FLOPs per launch / average launch duration."""
-    real = ops.gemm
+    GEMM launch of one extra step: achieved = algorithmic FLOPs per launch / average launch duration.  With --dtype fp8 the
+    dominant kernel is the fp8 GEMM (eavqa_gemm_fp8, priced against the 5 PFLOP/s dense fp8 peak); the bf16 launches of that run
+    (mapper, CLIP tower) are reported beside it."""
+    real, real8 = ops.gemm, ops.gemm_fp8
     recs = []
 
-    def timed(a, b, *, a_kc=True, b_kc=True, **kw):
-        M, K = a.shape if a_kc else (a.shape[1], a.shape[0])
-        N = b.shape[0] if b_kc else b.shape[1]
+    def bracket(kind, flops, bytes_, call):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = real(a, b, a_kc=a_kc, b_kc=b_kc, **kw)
+        out = call()
         e1.record()
         # an empty pair right behind it: what two event markers cost by themselves on this stream (subtracted below)
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record()
         c1.record()
-        recs.append((2.0 * M * N * K, e0, e1, c0, c1))
+        recs.append((kind, flops, bytes_, e0, e1, c0, c1))
         return out
 
-    ops.gemm = timed
+    def timed(a, b, *, a_kc=True, b_kc=True, **kw):
+        M, K = a.shape if a_kc else (a.shape[1], a.shape[0])
+        N = b.shape[0] if b_kc else b.shape[1]
+        o = kw.get("out")
+        out_b = 4 if (kw.get("out_f32") or (o is not None and o.dtype == torch.float32)) else a.element_size()
+        aux_b = a.element_size() if (kw.get("aux_in") is not None or kw.get("aux_out") is not None) else 0
+        res_b = 4 if kw.get("residual") is not None else 0
+        algo = (M * K + N * K) * a.element_size() + M * N * (out_b + aux_b + res_b)
+        return bracket("bf16", 2.0 * M * N * K, algo, lambda: real(a, b, a_kc=a_kc, b_kc=b_kc, **kw))
+
+    def timed8(aq, a_scale, bq, b_scale, **kw):
+        M, K = aq.shape
+        N = bq.shape[0]
+        o = kw.get("out")
+        out_b = 4 if (kw.get("out_f32") or (o is not None and o.dtype == torch.float32)) else 2
+        aux_b = 2 if (kw.get("aux_in") is not None or kw.get("aux_out") is not None) else 0
+        res_b = 4 if kw.get("residual") is not None else 0
+        algo = (M * K + N * K) + M * N * (out_b + aux_b + res_b)
+        return bracket("fp8", 2.0 * M * N * K, algo, lambda: real8(aq, a_scale, bq, b_scale, **kw))
+
+    ops.gemm, ops.gemm_fp8 = timed, timed8
     try:
         # head start: keep the GPU busy for ~60 ms so that the whole instrumented step is enqueued before the GPU
         # reaches it - the event pairs then bracket pure device time, not host latency between record and launch
@@ -449,26 +491,47 @@ def gemm_roofline(stepper, ops, workload="cfg2"):
         stepper.flush()
         torch.cuda.synchronize()
     finally:
-        ops.gemm = real
-    flops = sum(r[0] for r in recs)
-    n = len(recs)
-    raw = sum(r[1].elapsed_time(r[2]) for r in recs) * 1e-3
-    marker = sum(r[3].elapsed_time(r[4]) for r in recs) * 1e-3          # event-marker cost, per pair on average marker / n
-    secs = max(raw - marker, 0.5 * raw)
-    achieved = flops / secs / 1e12
-    peak = 2500.0 if stepper.model.dtype == torch.bfloat16 else 157.3
-    # HBM bytes per GEMM launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-    # in separate runs, FETCH_SIZE x 2 on gfx950, KiB units): tools/pmc_traffic.py -> profiles/round1_gemm_traffic.json
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "round1_gemm_traffic.json")
-    if workload == "cfg2" and stepper.model.dtype == torch.bfloat16 and os.path.exists(tfile):
+        ops.gemm, ops.gemm_fp8 = real, real8
+
+    def summarise(kind, peak):
+        rs = [r for r in recs if r[0] == kind]
+        if not rs:
+            return None
+        flops, algo, n = sum(r[1] for r in rs), sum(r[2] for r in rs), len(rs)
+        raw = sum(r[3].elapsed_time(r[4]) for r in rs) * 1e-3
+        marker = sum(r[5].elapsed_time(r[6]) for r in rs) * 1e-3      # event-marker cost, per pair on average marker / n
+        secs = max(raw - marker, 0.5 * raw)
+        ach = flops / secs / 1e12
+        return {"achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "launches_per_step": n,
+                "gflop_per_launch": round(flops / n / 1e9, 2), "avg_launch_us": round(secs / n * 1e6, 2),
+                "event_marker_us": round(marker / n * 1e6, 2), "gemm_ms_per_step": round(secs * 1e3, 3),
+                "algorithmic_bytes_per_launch": round(algo / n)}
+
+    if dtype_name == "f32":
+        r = summarise("bf16", 157.3)
+        return {"bound": "mfma", "kernel": "eavqa_gemm: gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", **r, "traffic": None}
+    main_kind = "fp8" if dtype_name == "fp8" else "bf16"
+    r = summarise(main_kind, 5000.0 if main_kind == "fp8" else 2500.0)
+    # HBM bytes per GEMM launch from committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    # runs, FETCH_SIZE x 2 on gfx950, KiB units; tools/pmc_traffic.py).  The file carries the digest of the GEMM sources it was
+    # measured on: with other sources the figure is dropped, not reused.
+    traffic, traffic_source = None, None
+    tfile = os.path.join(ROOT, "profiles", f"round2_gemm_traffic_{workload}_{dtype_name}.json")
+    if os.path.exists(tfile):
         with open(tfile) as f:
-            traffic = round(json.load(f)["bytes_per_launch"])
-    return {"bound": "mfma", "kernel": "eavqa_gemm: gemm_bf16_shaped_kernel (128x80 / 256x128 / 256x160 / 256x192 tiles) + gemm_bf16_big / fast / skinny"
-            if stepper.model.dtype == torch.bfloat16 else "gemm_f32_kernel",
-            "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-            "launches_per_step": n, "gflop_per_launch": round(flops / n / 1e9, 2), "avg_launch_us": round(secs / n * 1e6, 2),
-            "event_marker_us": round(marker / n * 1e6, 2), "gemm_ms_per_step": round(secs * 1e3, 3)}
+            t = json.load(f)
+        if t.get("gemm_source_digest") == gemm_source_digest():
+            traffic, traffic_source = round(t["bytes_per_launch"]), f"profiles/{os.path.basename(tfile)} @ gemm sources {t['gemm_source_digest']}"
+        else:
+            traffic_source = f"dropped: {os.path.basename(tfile)} was measured on gemm sources {t.get('gemm_source_digest')}, this run is {gemm_source_digest()}"
+    kernel = ("eavqa_gemm_fp8: gemm_fp8_k128s_kernel (v_mfma_scale_f32_16x16x128_f8f6f4, loader / consumer specialised full-line tiles)"
+              if main_kind == "fp8" else
+              "eavqa_gemm: gemm_bf16_k64s_kernel (loader / consumer specialised full-line tiles 128x80 / 256x128 / 256x160 / 128x128 / 128x256) "
+              "+ gemm_bf16_big_kernel (256x256)")
+    out = {"bound": "mfma", "kernel": kernel, **r, "traffic": traffic, "traffic_source": traffic_source}
+    if main_kind == "fp8":
+        out["bf16_gemms_same_step"] = summarise("bf16", 2500.0)
+    return out
 
 
 if __name__ == "__main__":

@@ -122,6 +122,15 @@ def mapper_project(prefix: Tensor, mapper: Dict[str, Tensor], mapping_type: str,
 # --------------------------------------------------------------------------
 # causal LMs (HF GPT-2 / OPT)
 # --------------------------------------------------------------------------
+def _lin(cfg: dict, x: Tensor, w_out_in: Tensor, b: Optional[Tensor]) -> Tensor:
+    """``x @ w^T + b`` (``w`` as ``[out, in]``).  ``cfg["linear_fn"]``, when present, replaces the product: the fp8 numerics
+    model of oracle/fp8_sim.py plugs in there so that the LM code below stays the single restatement of HF's forward."""
+    fn = cfg.get("linear_fn")
+    y = fn(x, w_out_in) if fn is not None else x @ w_out_in.T
+    return y if b is None else y + b
+
+
+
 def attention_bias(attention_mask: Tensor, causal: bool = True) -> Tensor:
     """Additive ``[B,1,S,S]`` bias: ``finfo.min`` where the key is padded or (causal) in
     the future, else 0 - what HF's eager path adds (HF:models/gpt2/modeling_gpt2.py:54-72,
@@ -157,23 +166,23 @@ def gpt2_hidden(sd: Dict[str, Tensor], cfg: dict, inputs_embeds: Tensor, attenti
     for i in range(cfg["n_layer"]):
         p = f"transformer.h.{i}."
         a = layer_norm(h, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"], eps)
-        qkv = a @ sd[p + "attn.c_attn.weight"] + sd[p + "attn.c_attn.bias"]
+        qkv = _lin(cfg, a, sd[p + "attn.c_attn.weight"].T, sd[p + "attn.c_attn.bias"])
         q, k, v = qkv.split(E, dim=2)
         q = q.view(B, S, H, hd).transpose(1, 2)
         k = k.view(B, S, H, hd).transpose(1, 2)
         v = v.view(B, S, H, hd).transpose(1, 2)
         ctx = _sdpa(q, k, v, bias, hd ** -0.5).transpose(1, 2).reshape(B, S, E)
-        h = h + (ctx @ sd[p + "attn.c_proj.weight"] + sd[p + "attn.c_proj.bias"])
+        h = h + _lin(cfg, ctx, sd[p + "attn.c_proj.weight"].T, sd[p + "attn.c_proj.bias"])
         m = layer_norm(h, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"], eps)
-        m = act(m @ sd[p + "mlp.c_fc.weight"] + sd[p + "mlp.c_fc.bias"])
-        h = h + (m @ sd[p + "mlp.c_proj.weight"] + sd[p + "mlp.c_proj.bias"])
+        m = act(_lin(cfg, m, sd[p + "mlp.c_fc.weight"].T, sd[p + "mlp.c_fc.bias"]))
+        h = h + _lin(cfg, m, sd[p + "mlp.c_proj.weight"].T, sd[p + "mlp.c_proj.bias"])
     return layer_norm(h, sd["transformer.ln_f.weight"], sd["transformer.ln_f.bias"], eps)
 
 
 def gpt2_logits(sd, cfg, inputs_embeds, attention_mask) -> Tensor:
     """``GPT2LMHeadModel`` lm_head (tied to wte, no bias) HF:...modeling_gpt2.py:698."""
     w = sd.get("lm_head.weight", sd["transformer.wte.weight"])
-    return gpt2_hidden(sd, cfg, inputs_embeds, attention_mask) @ w.T
+    return _lin(cfg, gpt2_hidden(sd, cfg, inputs_embeds, attention_mask), w, None)
 
 
 def opt_hidden(sd: Dict[str, Tensor], cfg: dict, inputs_embeds: Tensor, attention_mask: Tensor) -> Tensor:
@@ -193,24 +202,24 @@ def opt_hidden(sd: Dict[str, Tensor], cfg: dict, inputs_embeds: Tensor, attentio
     for i in range(cfg["n_layer"]):
         p = f"{pre}layers.{i}."
         a = layer_norm(h, sd[p + "self_attn_layer_norm.weight"], sd[p + "self_attn_layer_norm.bias"], eps)
-        q = (a @ sd[p + "self_attn.q_proj.weight"].T + sd[p + "self_attn.q_proj.bias"]) * (hd ** -0.5)
-        k = a @ sd[p + "self_attn.k_proj.weight"].T + sd[p + "self_attn.k_proj.bias"]
-        v = a @ sd[p + "self_attn.v_proj.weight"].T + sd[p + "self_attn.v_proj.bias"]
+        q = _lin(cfg, a, sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]) * (hd ** -0.5)
+        k = _lin(cfg, a, sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.k_proj.bias"])
+        v = _lin(cfg, a, sd[p + "self_attn.v_proj.weight"], sd[p + "self_attn.v_proj.bias"])
         q = q.view(B, S, H, hd).transpose(1, 2)
         k = k.view(B, S, H, hd).transpose(1, 2)
         v = v.view(B, S, H, hd).transpose(1, 2)
         ctx = _sdpa(q, k, v, bias, 1.0).transpose(1, 2).reshape(B, S, E)
-        h = h + (ctx @ sd[p + "self_attn.out_proj.weight"].T + sd[p + "self_attn.out_proj.bias"])
+        h = h + _lin(cfg, ctx, sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"])
         m = layer_norm(h, sd[p + "final_layer_norm.weight"], sd[p + "final_layer_norm.bias"], eps)
-        m = act(m @ sd[p + "fc1.weight"].T + sd[p + "fc1.bias"])
-        h = h + (m @ sd[p + "fc2.weight"].T + sd[p + "fc2.bias"])
+        m = act(_lin(cfg, m, sd[p + "fc1.weight"], sd[p + "fc1.bias"]))
+        h = h + _lin(cfg, m, sd[p + "fc2.weight"], sd[p + "fc2.bias"])
     return layer_norm(h, sd[pre + "final_layer_norm.weight"], sd[pre + "final_layer_norm.bias"], eps)
 
 
 def opt_logits(sd, cfg, inputs_embeds, attention_mask) -> Tensor:
     """``OPTForCausalLM`` lm_head HF:models/opt/modeling_opt.py:443-538 (tied, no bias)."""
     w = sd.get("lm_head.weight", sd["model.decoder.embed_tokens.weight"])
-    return opt_hidden(sd, cfg, inputs_embeds, attention_mask) @ w.T
+    return _lin(cfg, opt_hidden(sd, cfg, inputs_embeds, attention_mask), w, None)
 
 
 def lm_logits(sd, cfg, inputs_embeds, attention_mask) -> Tensor:
