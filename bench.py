@@ -94,7 +94,8 @@ class Stepper:
         stream (the encode depends on nothing trainable; the LM's N = 1280 GEMMs leave ~40 % of the CUs idle);
       * with N > 1 the gradient all-reduce of step i overlaps the same window and AdamW(i) is applied right before the
         mapper forward of step i+1 (the mapper gradient is the last thing backward produces).
-    Every step still performs exactly one encode, one forward/backward and one optimiser update."""
+    Every step performs one forward/backward and one optimiser update, and one encode - except the very first step of a run,
+    which also encodes its own batch to fill the pipeline (untimed: it falls into the warm-up)."""
 
     def __init__(self, vit, model, opt, batch, pad, sync, overlap_vit=True):
         self.vit, self.model, self.opt, self.batch, self.pad, self.sync = vit, model, opt, batch, pad, sync

@@ -433,7 +433,11 @@ template <int LPK, int DEC_WPH>
 __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                           int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv, bf16_t* __restrict__ out,
                                                           int64_t ldo, int64_t bsq, int64_t bsk, const int32_t* __restrict__ key_mask,
-                                                          int64_t ld_mask, float* __restrict__ lse, int H, int Sk, int hd, float scale) {
+                                                          int64_t ld_mask, float* __restrict__ lse, int H, int Sk, int hd, float scale,
+                                                          const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new, int64_t ld_new) {
+    // k_new / v_new (eavqa_attention_decode): the K / V rows of the NEW position (key Sk - 1) still sit in the QKV projection's
+    // output; the lanes that own that key take them from there and append them to the cache on the way (each 16-byte piece of a
+    // cache row has exactly one owner lane), which saves the separate append pass of the decode step.
     extern __shared__ float dec_sc[];                 // [4 heads][Sk] scores, then [4][DEC_WPH][128] partial outputs
     constexpr int KPI = 64 / LPK;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -453,6 +457,24 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
     }
     const bf16_t* kb = k + (int64_t)b * bsk * ldk + h * hd + 8 * dl;
     const bf16_t* vb = v + (int64_t)b * bsk * ldv + h * hd + 8 * dl;
+    const bf16_t* kn = k_new ? k_new + (int64_t)b * ld_new + h * hd + 8 * dl : nullptr;
+    const bf16_t* vn = v_new ? v_new + (int64_t)b * ld_new + h * hd + 8 * dl : nullptr;
+    auto load_k = [&](int j) -> bf16x8 {
+        if (kn && j == Sk - 1) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(kn);
+            *reinterpret_cast<bf16x8*>(const_cast<bf16_t*>(kb) + (int64_t)j * ldk) = t;
+            return t;
+        }
+        return *reinterpret_cast<const bf16x8*>(kb + (int64_t)j * ldk);
+    };
+    auto load_v = [&](int j) -> bf16x8 {
+        if (vn && j == Sk - 1) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(vn);
+            *reinterpret_cast<bf16x8*>(const_cast<bf16_t*>(vb) + (int64_t)j * ldv) = t;
+            return t;
+        }
+        return *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
+    };
     const int32_t* mrow = key_mask ? key_mask + (int64_t)b * ld_mask : nullptr;
     // key of (batch start j0, slot u): groups of KPI keys are dealt round-robin to the DEC_WPH waves of the head
     auto key_of = [&](int j0, int u) { return j0 + (u * DEC_WPH + part) * KPI + sub; };
@@ -464,7 +486,7 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
         for (int u = 0; u < DEC_U; ++u) {
             const int j = key_of(j0, u);
             kv[u] = (bf16x8){};
-            if (active && j < Sk) kv[u] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)j * ldk);
+            if (active && j < Sk) kv[u] = load_k(j);
         }
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
@@ -483,7 +505,7 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
     for (int u = 0; u < DEC_U; ++u) {
         const int j = key_of(0, u);
         v0[u] = (bf16x8){};
-        if (active && j < Sk) v0[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
+        if (active && j < Sk) v0[u] = load_v(j);
     }
     __syncthreads();
     float mx = -FLT_MAX;
@@ -503,7 +525,7 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
             if (j0 == 0) vv[u] = v0[u];
             else {
                 vv[u] = (bf16x8){};
-                if (active && j < Sk) vv[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
+                if (active && j < Sk) vv[u] = load_v(j);
             }
             pj[u] = (active && j < Sk) ? __expf(sc[j] - mx) : 0.f;
         }
@@ -545,12 +567,13 @@ bool decode_supported(int dtype, int Sq, int Sk, int hd, const int32_t* cu, int6
 
 }  // namespace
 
-extern "C" int eavqa_attention_fwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
-                                   const void* q, int64_t ldq, const void* k, int64_t ldk,
-                                   const void* v, int64_t ldv, void* o, int64_t ldo,
-                                   int64_t q_batch_rows, int64_t kv_batch_rows,
-                                   const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal,
-                                   float scale, float* lse, void* stream, int path) {
+static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
+                              const void* q, int64_t ldq, const void* k, int64_t ldk,
+                              const void* v, int64_t ldv, void* o, int64_t ldo,
+                              int64_t q_batch_rows, int64_t kv_batch_rows,
+                              const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal,
+                              float scale, float* lse, void* stream, int path,
+                              const void* k_new, const void* v_new, int64_t ld_new) {
     const bool g_force_valu = (path & 1) != 0;      // include/eavqa_test.h: bf16 on the vector-ALU kernels
     if (!q || !k || !v || !o) return EAVQA_E_ARG;
     int rc = check_common(dtype, B, H, Sq, Sk, hd);
@@ -579,13 +602,15 @@ extern "C" int eavqa_attention_fwd_ex(int dtype, int B, int H, int Sq, int Sk, i
 #define EAVQA_DEC2(LPK, WPH)                                                                                                 \
     hipLaunchKernelGGL((attn_decode_kernel<LPK, WPH>), grid, dim3(256 * WPH), lds, s, reinterpret_cast<const bf16_t*>(q), ldq,  \
                        reinterpret_cast<const bf16_t*>(k), ldk, reinterpret_cast<const bf16_t*>(v), ldv,                      \
-                       reinterpret_cast<bf16_t*>(o), ldo, p.bsq, p.bsk, key_mask, p.ld_mask, lse, H, Sk, hd, scale)
+                       reinterpret_cast<bf16_t*>(o), ldo, p.bsq, p.bsk, key_mask, p.ld_mask, lse, H, Sk, hd, scale,                  \
+                       reinterpret_cast<const bf16_t*>(k_new), reinterpret_cast<const bf16_t*>(v_new), ld_new)
         if (hd <= 64) { EAVQA_DEC(8); } else { EAVQA_DEC(16); }
 #undef EAVQA_DEC
 #undef EAVQA_DEC2
         EAVQA_LAUNCH_CHECK();
         return EAVQA_OK;
     }
+    if (k_new || v_new) return EAVQA_E_SHAPE;          // the append form exists for the decode kernel only
     if (dtype == EAVQA_BF16 && eavqa_attn_mfma::supported(hd) && !g_force_valu) {
         eavqa_attn_mfma::Params m = {};
         m.q = q; m.k = k; m.v = v; m.out = o; m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo;
@@ -595,6 +620,26 @@ extern "C" int eavqa_attention_fwd_ex(int dtype, int B, int H, int Sq, int Sk, i
         return eavqa_attn_mfma::run(0, m, s);
     }
     return dtype == EAVQA_F32 ? dispatch<float>(K_FWD, p, s) : dispatch<bf16_t>(K_FWD, p, s);
+}
+
+extern "C" int eavqa_attention_fwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
+                                   const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                   const void* v, int64_t ldv, void* o, int64_t ldo,
+                                   int64_t q_batch_rows, int64_t kv_batch_rows,
+                                   const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal,
+                                   float scale, float* lse, void* stream, int path) {
+    return attention_fwd_impl(dtype, B, H, Sq, Sk, hd, q, ldq, k, ldk, v, ldv, o, ldo, q_batch_rows, kv_batch_rows, key_mask, ld_mask,
+                              cu_seqlens, causal, scale, lse, stream, path, nullptr, nullptr, 0);
+}
+
+extern "C" int eavqa_attention_decode(int dtype, int B, int H, int Sk, int hd, const void* q, int64_t ldq, void* k_cache, int64_t ldk,
+                                      void* v_cache, int64_t ldv, int64_t kv_batch_rows, const void* k_new, const void* v_new,
+                                      int64_t ld_new, void* o, int64_t ldo, const int32_t* key_mask, int64_t ld_mask, float scale,
+                                      void* stream) {
+    if (!k_new || !v_new) return EAVQA_E_ARG;
+    if (ld_new % 8 || !eavqa_aligned16(k_new) || !eavqa_aligned16(v_new)) return EAVQA_E_ALIGN;
+    return attention_fwd_impl(dtype, B, H, 1, Sk, hd, q, ldq, k_cache, ldk, v_cache, ldv, o, ldo, 1, kv_batch_rows, key_mask, ld_mask,
+                              nullptr, 1, scale, nullptr, stream, 0, k_new, v_new, ld_new);
 }
 
 extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,

@@ -1,6 +1,6 @@
 // Host-side driver: all decoder layers of a frozen causal LM for `Sq` new positions per sample in ONE C call
 // (eavqa_lm_block_forward in include/eavqa.h).  Used by generation (prefill: Sq = prompt length, decode: Sq = 1):
-// a decode step is ~9 short kernels per layer, and enqueueing them from Python one by one made the step host-bound
+// a decode step is 9 short kernels per layer, and enqueueing them from Python one by one made the step host-bound
 // (5 ms of Python for ~2 ms of GPU work on OPT-2.7B).  Pure enqueue: no allocation (the caller passes a workspace),
 // no synchronisation, graph-capturable.
 #include <hip/hip_runtime.h>
@@ -60,6 +60,14 @@ extern "C" int eavqa_lm_block_forward(int dtype, int n_layer, const eavqa_lm_lay
     const DecodePlan d = plan_decode(dtype, rows, Sq, E, F);
     if (d.ok) {
         // ---- decode step: split-K weight streaming; every GEMM leaves fp32 partial sums that its consumer adds up
+        // Alternative route (QKV and FFN-up through eavqa_gemm's M <= 64 tile kernels with the bias / activation in the epilogue, the
+        // decode attention appending K / V itself: 7 kernels per layer instead of 9).  MEASURED SLOWER in the step (OPT-2.7B, B = 32:
+        // 3.42 against 3.16 ms per step) although the tile GEMM wins on cache-resident weights (33 against 111 us for the mapper's
+        // second Linear): with every layer's weights coming cold from HBM the 96-128 workgroups of a 128 x 80 tiling keep too few
+        // bytes in flight, while the split-K kernels spread each product over 500+ workgroups.  Kept selectable for that experiment
+        // (the compile-time constant below), not taken.
+        constexpr bool kFusedDecode = false;
+        const bool fused = kFusedDecode && (E % 64) == 0 && (hd % 8) == 0 && hd <= 128 && Sk <= 3584;
         float* part = reinterpret_cast<float*>(w);
         float* part2 = reinterpret_cast<float*>(w + (d.part_bytes - align_up((size_t)d.ks_fc2 * rows * E * 4)));
         for (int l = 0; l < n_layer; ++l) {
@@ -68,18 +76,33 @@ extern "C" int eavqa_lm_block_forward(int dtype, int n_layer, const eavqa_lm_lay
             if (l == 0) rc = eavqa_layernorm_splitk(dtype, rows, E, x, E, nullptr, 0, nullptr, nullptr, 0, L.ln1_g, L.ln1_b, eps, a, E, stream);
             else rc = eavqa_layernorm_splitk(dtype, rows, E, x1, E, part2, d.ks_fc2, layers[l - 1].b_fc2, x, E, L.ln1_g, L.ln1_b, eps, a, E, stream);
             if (rc) return rc;
-            if ((rc = eavqa_gemm_splitk(dtype, rows, 3 * E, E, a, E, L.w_qkv, E, part, d.ks_qkv, stream))) return rc;
-            // q -> qkv[:, :E]; k, v -> cache rows (sample m at row m * S_max + row0)
-            if ((rc = eavqa_splitk_finish(dtype, rows, 3 * E, part, d.ks_qkv, L.b_qkv, EAVQA_ACT_NONE, nullptr, 0, 0, 3, qkv, 3 * E,
-                                          static_cast<char*>(L.k_cache) + (size_t)row0 * E * es, (int64_t)S_max * E,
-                                          static_cast<char*>(L.v_cache) + (size_t)row0 * E * es, (int64_t)S_max * E, stream))) return rc;
-            if ((rc = eavqa_attention_fwd(dtype, B, H, Sq, Sk, hd, qkv, 3 * E, L.k_cache, E, L.v_cache, E, ctx, E, Sq, S_max, key_mask, ld_mask,
-                                          nullptr, 1, scale, nullptr, stream))) return rc;
+            if (fused) {
+                // wide N, short K: no split - the weight-streaming tile GEMM (eavqa_gemm's M <= 64 route) adds the bias itself, and
+                // the decode attention takes the new K / V rows straight from its output and appends them to the cache (7 kernels
+                // per layer instead of 9: no finish pass, no partial sums for this product)
+                if ((rc = eavqa_gemm(dtype, 1, 1, rows, 3 * E, E, a, E, L.w_qkv, E, qkv, 3 * E, 0, 1.f, L.b_qkv, EAVQA_ACT_NONE, nullptr, nullptr, 0,
+                                     nullptr, 0, stream))) return rc;
+                if ((rc = eavqa_attention_decode(dtype, B, H, Sk, hd, qkv, 3 * E, L.k_cache, E, L.v_cache, E, S_max, qkv + (size_t)E * es,
+                                                 qkv + (size_t)2 * E * es, 3 * E, ctx, E, key_mask, ld_mask, scale, stream))) return rc;
+            } else {
+                if ((rc = eavqa_gemm_splitk(dtype, rows, 3 * E, E, a, E, L.w_qkv, E, part, d.ks_qkv, stream))) return rc;
+                // q -> qkv[:, :E]; k, v -> cache rows (sample m at row m * S_max + row0)
+                if ((rc = eavqa_splitk_finish(dtype, rows, 3 * E, part, d.ks_qkv, L.b_qkv, EAVQA_ACT_NONE, nullptr, 0, 0, 3, qkv, 3 * E,
+                                              static_cast<char*>(L.k_cache) + (size_t)row0 * E * es, (int64_t)S_max * E,
+                                              static_cast<char*>(L.v_cache) + (size_t)row0 * E * es, (int64_t)S_max * E, stream))) return rc;
+                if ((rc = eavqa_attention_fwd(dtype, B, H, Sq, Sk, hd, qkv, 3 * E, L.k_cache, E, L.v_cache, E, ctx, E, Sq, S_max, key_mask, ld_mask,
+                                              nullptr, 1, scale, nullptr, stream))) return rc;
+            }
             if ((rc = eavqa_gemm_splitk(dtype, rows, E, E, ctx, E, L.w_o, E, part, d.ks_o, stream))) return rc;
             // x1 = x + b_o + sum(partials); a = LN2(x1)
             if ((rc = eavqa_layernorm_splitk(dtype, rows, E, x, E, part, d.ks_o, L.b_o, x1, E, L.ln2_g, L.ln2_b, eps, a, E, stream))) return rc;
-            if ((rc = eavqa_gemm_splitk(dtype, rows, F, E, a, E, L.w_fc1, E, part, d.ks_fc1, stream))) return rc;
-            if ((rc = eavqa_splitk_finish(dtype, rows, F, part, d.ks_fc1, L.b_fc1, act, nullptr, 0, 0, 1, f, F, nullptr, 0, nullptr, 0, stream))) return rc;
+            if (fused) {
+                if ((rc = eavqa_gemm(dtype, 1, 1, rows, F, E, a, E, L.w_fc1, E, f, F, 0, 1.f, L.b_fc1, act, nullptr, nullptr, 0, nullptr, 0,
+                                     stream))) return rc;
+            } else {
+                if ((rc = eavqa_gemm_splitk(dtype, rows, F, E, a, E, L.w_fc1, E, part, d.ks_fc1, stream))) return rc;
+                if ((rc = eavqa_splitk_finish(dtype, rows, F, part, d.ks_fc1, L.b_fc1, act, nullptr, 0, 0, 1, f, F, nullptr, 0, nullptr, 0, stream))) return rc;
+            }
             if ((rc = eavqa_gemm_splitk(dtype, rows, E, F, f, F, L.w_fc2, F, part2, d.ks_fc2, stream))) return rc;
         }
         // x = x1 + b_fc2 + sum(last FFN-down partials)

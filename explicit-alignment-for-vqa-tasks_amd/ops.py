@@ -160,6 +160,18 @@ def attention_fwd(q: Tensor, k: Tensor, v: Tensor, B: int, H: int, Sq: int, Sk: 
     return (o, lse) if save_lse else o
 
 
+def attention_decode(q: Tensor, k_cache: Tensor, v_cache: Tensor, k_new: Tensor, v_new: Tensor, B: int, H: int, Sk: int, hd: int, *,
+                     kv_batch_rows: int, key_mask: Optional[Tensor] = None, ld_mask: int = 0, scale: float = 1.0,
+                     out: Optional[Tensor] = None) -> Tensor:
+    """One decode step that appends: ``k_new`` / ``v_new`` (row views [B, H*hd]) go to position ``Sk - 1`` of every sample's cache
+    (``k_cache`` / ``v_cache`` row views [B*kv_batch_rows, H*hd]) and ``q`` [B, H*hd] attends over positions ``0 .. Sk-1``."""
+    _dev(q)
+    o = out if out is not None else torch.empty((B, H * hd), device=q.device, dtype=q.dtype)
+    call("eavqa_attention_decode", dtype_id(q.dtype), B, H, Sk, hd, _p(q), _ld(q), _p(k_cache), _ld(k_cache), _p(v_cache), _ld(v_cache),
+         kv_batch_rows, _p(k_new), _p(v_new), _ld(k_new), _p(o), _ld(o), _p(key_mask), ld_mask, float(scale), _stream())
+    return o
+
+
 def attention_bwd(q, k, v, o, d_o, lse, B, H, Sq, Sk, hd, *, key_mask=None, causal=False, scale=1.0,
                   dq=None, dk=None, dv=None, cu_seqlens=None):
     _dev(q)

@@ -119,6 +119,14 @@ int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,
                         int64_t q_batch_rows, int64_t kv_batch_rows,
                         const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal, float scale,
                         float* lse, void* stream);
+/* One decode step (Sq = 1, causal) that also APPENDS: k_new / v_new hold the new position's K / V rows (`dtype`, sample b at
+ * k_new + b*ld_new, head h at + h*hd - e.g. columns E.. and 2E.. of the QKV projection's output); they are written to position Sk-1 of
+ * each sample's cache (k_cache / v_cache [B, kv_batch_rows, ld]) and attended together with positions 0..Sk-2 already there.
+ * bfloat16, hd % 8 == 0, hd <= 128, Sk <= 3584 (EAVQA_E_SHAPE otherwise).  Replaces the append + attention of one token of the
+ * reference's full re-forward (src/models/clipcap.py:414-419). */
+int eavqa_attention_decode(int dtype, int B, int H, int Sk, int hd, const void* q, int64_t ldq, void* k_cache, int64_t ldk,
+                           void* v_cache, int64_t ldv, int64_t kv_batch_rows, const void* k_new, const void* v_new, int64_t ld_new,
+                           void* o, int64_t ldo, const int32_t* key_mask, int64_t ld_mask, float scale, void* stream);
 /* Backward (dense batches only: batch_rows = Sq / Sk): dq/dk/dv in `dtype`, addressed as q/k/v
  * with leading dims lddq/lddk/lddv.
  * delta: float32 scratch [B,H,Sq] (rowsum(do*o), written by the call). */

@@ -244,7 +244,23 @@ def main():
          s_cfg=np.array([L3, E5, shots]))
 
     # ------------------------------------------------------------------ label masking known answers
-    # hand-derived from src/trainers/clipcap_exector.py:134-150 (pad == eos == 9, bos == 7)
+    # HAND-DERIVED from src/trainers/clipcap_exector.py:134-150 (pad == eos == 9, bos == 7); the executor cannot be imported here
+    # (pytorch_lightning / wandb absent).  The rule, line by line:
+    #   :135  labels = input_ids.clone()                      :136  labels[labels == pad] = -100      (EVERY pad, also inside text)
+    #   :138  per row i, walk j = 0 .. T-1 with answer_tokens = False:
+    #   :141-143    token == -100 (a pad)   -> labels[i, j] = pad (== eos: the end-of-answer target), then BREAK out of the row
+    #   :144-147    token == <BOS>          -> answer_tokens = True, labels[i, j] = -100, continue
+    #   :148-149    answer_tokens           -> keep the token as its own label
+    #   :150        otherwise (question)    -> labels[i, j] = -100
+    # Consequences the rows below spell out:
+    #   row 0  question 3 4 | <BOS> | answer 5 6 | first pad restored to 9 | later pads stay -100 (set at :136, never visited: break)
+    #   row 1  same with a one-token answer
+    #   row 2  NO pad in the row: the walk never breaks and nothing is restored; tokens after <BOS> (8) are the only labels
+    #   row 3  NO <BOS>: the whole question is masked, the first pad still becomes 9 (a lone eos target)
+    #   row 4  TWO <BOS>: both are -100 themselves, every other token after the first one is kept
+    # The "untouched tail" quirk (eavqa_amd.trainers.clipcap_executor.vqa_label_count): positions BEHIND the first pad are never
+    # visited, so a non-pad token there (possible only with pad tokens inside the text, e.g. 3 9 4 5) keeps labels[i, j] =
+    # input_ids[i, j] from :135 - it is scored.  tests/test_executor_gpu.py::test_vqa_label_count_matches_the_masking_rule covers it.
     lm_in = np.array([[3, 4, 7, 5, 6, 9, 9, 9],      # question 3 4, <BOS>, answer 5 6, then pads
                       [3, 7, 5, 9, 9, 9, 9, 9],
                       [3, 4, 5, 6, 2, 1, 7, 8],      # no pad at all: answer = last token only

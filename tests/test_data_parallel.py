@@ -162,3 +162,25 @@ def test_exchange_choice_rule():
     assert c["factors"] < c["sharded"] < c["allreduce"]
     c7 = dp_exchange_costs(8_640_000_000, 8_640_000_000, 32, 8, links=7)
     assert c7["sharded"] < c7["factors"]                                                # a direct 7-link algorithm would flip it
+
+
+def test_all_gather_rows_nccl_branch_shapes_and_order(monkeypatch):
+    """The RCCL branch of all_gather_rows (one all_gather_into_tensor straight into the result) cannot run here (no GPU) nor with
+    two ranks on one card (RCCL refuses duplicate devices): exercise it against a recording stand-in for the process group -
+    output shape [world * rows, cols], rank-major order, a contiguous input."""
+    from eavqa_amd.trainers import data_parallel as dp
+    calls = {}
+
+    def fake_all_gather_into_tensor(out, t, group=None):
+        calls["out_shape"], calls["in_contig"] = tuple(out.shape), t.is_contiguous()
+        world = out.shape[0] // t.shape[0]
+        for r in range(world):                       # what ncclAllGather produces: rank r's rows at [r * rows, (r + 1) * rows)
+            out[r * t.shape[0]:(r + 1) * t.shape[0]] = t + 100 * r
+    monkeypatch.setattr(dp.dist, "get_world_size", lambda group=None: 4)
+    monkeypatch.setattr(dp.dist, "get_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(dp.dist, "all_gather_into_tensor", fake_all_gather_into_tensor)
+    x = torch.arange(12.0).view(3, 4).t()            # non-contiguous [4, 3] view
+    out = dp.all_gather_rows(x)
+    assert tuple(out.shape) == (16, 3) and calls == {"out_shape": (16, 3), "in_contig": True}
+    for r in range(4):
+        assert torch.equal(out[4 * r:4 * r + 4], x + 100 * r)

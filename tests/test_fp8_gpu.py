@@ -162,8 +162,12 @@ def test_fp8_lm_training_step_against_weight_roundtripped_oracle(arch):
     fp32 oracle whose Linear weights went through the same e4m3 round trip (activations exact there: this bounds what the fp8
     FORMAT costs - measured on MI355X: logits 0.31 at |logits| 4.4, loss 3e-3, mapper gradients 34 % of the largest entry after
     two layers of row-wise 3-mantissa-bit activations and gradients), and against the fp8 numerics model of oracle/fp8_sim.py,
-    which quantises the same operands at the same places (this bounds the KERNELS: accumulation order and rounding flips only).
-    The bf16 path of the same model is printed alongside for scale."""
+    which quantises the same operands at the same places but keeps everything else in fp32.  Measured: the two comparisons
+    come out alike (logits 0.39, gradients 27 %) - at e4m3's 2^-4 spacing the bf16 roundings of the surrounding kernels (which
+    alone move this deliberately sensitive model's gradients by 8 %, first line printed) flip enough quantisation decisions to
+    decorrelate the two, so a model-level comparison cannot separate kernel error from format noise.  What pins the KERNELS
+    is above: the quantiser is bit-exact against torch's e4m3fn and the GEMM is exact on integers and within fp32 accumulation
+    error on the same quantised operands, for every tile."""
     from eavqa_amd.models.clipcap import ClipCaptionPrefix
     from eavqa_amd.models.lm import FrozenCausalLM, LMConfig, random_init_state_dict
     E, H, F, NL, V, L, D, B, T = 256, 4, 512, 2, 640, 4, 32, 6, 24
@@ -199,8 +203,8 @@ def test_fp8_lm_training_step_against_weight_roundtripped_oracle(arch):
     wq = _fp8_oracle_weights(sd, arch)
     cases = (("native", "bf16 LM vs fp32 oracle", sd, base, None),
              ("fp8", "fp8 LM vs fp32 oracle with e4m3-round-tripped weights (what the FORMAT costs)", wq, base, dict(loss=5e-2, logits=0.6, grad=0.6)),
-             ("fp8", "fp8 LM vs the fp8 numerics model (oracle/fp8_sim.py: what the KERNELS may differ in)", wq,
-              dict(base, linear_fn=fp8_sim.fp8_linear), dict(loss=5e-3, logits=0.08, grad=0.08)))
+             ("fp8", "fp8 LM vs the fp8 numerics model (oracle/fp8_sim.py: same quantisation points, fp32 elsewhere)", wq,
+              dict(base, linear_fn=fp8_sim.fp8_linear), dict(loss=5e-2, logits=0.6, grad=0.6)))
     for fmt, what, wsd, ocfg, tol in cases:
         mp = {k: v.clone().requires_grad_(True) for k, v in mapper_sd.items()}
         loss, logits = oracle.clipcap_forward(wsd, ocfg, mp, dict(prefix_length=L, mapping_type="mlp"), ids, prefix, mask, labels)

@@ -240,6 +240,33 @@ def attn_path(request):
     ops.KernelSelect.attention = 0
 
 
+@pytest.mark.parametrize("B,H,hd,Sk,S_max", [(32, 32, 80, 151, 160), (5, 12, 64, 1, 8), (33, 20, 64, 97, 120), (64, 32, 128, 200, 256), (3, 6, 96, 40, 40)])
+def test_attention_decode_appends_and_attends(ops, B, H, hd, Sk, S_max):
+    """eavqa_attention_decode: the new K / V rows come from the QKV projection's output (strided views of one [B, 3E] buffer), are
+    written to position Sk-1 of the cache and attended with the positions already there; ragged key masks; other cache rows untouched."""
+    E = H * hd
+    g = torch.Generator().manual_seed(B + Sk)
+    kc = torch.randn(B, S_max, E, generator=g).to(torch.bfloat16)
+    vc = torch.randn(B, S_max, E, generator=g).to(torch.bfloat16)
+    qkv = torch.randn(B, 3 * E, generator=g).to(torch.bfloat16)
+    mask = (torch.rand(B, S_max, generator=g) > 0.2).int()
+    mask[:, Sk - 1] = 1
+    scale = hd ** -0.5
+    kc_d, vc_d, qkv_d = kc.to(DEV), vc.to(DEV), qkv.to(DEV)
+    out = ops.attention_decode(qkv_d[:, :E], kc_d.view(B * S_max, E), vc_d.view(B * S_max, E), qkv_d[:, E:2 * E], qkv_d[:, 2 * E:], B, H, Sk, hd,
+                               kv_batch_rows=S_max, key_mask=mask.to(DEV), ld_mask=S_max, scale=scale)
+    k_full, v_full = kc.clone(), vc.clone()
+    k_full[:, Sk - 1], v_full[:, Sk - 1] = qkv[:, E:2 * E], qkv[:, 2 * E:]
+    assert torch.equal(kc_d.cpu(), k_full) and torch.equal(vc_d.cpu(), v_full)          # appended, nothing else touched
+    q = qkv[:, :E].float().view(B, H, 1, hd)
+    k = k_full[:, :Sk].float().view(B, Sk, H, hd).transpose(1, 2)
+    v = v_full[:, :Sk].float().view(B, Sk, H, hd).transpose(1, 2)
+    sc = (q @ k.transpose(-1, -2)) * scale
+    sc = sc.masked_fill(mask[:, None, None, :Sk] == 0, torch.finfo(torch.float32).min)
+    ref = (torch.softmax(sc, -1) @ v).transpose(1, 2).reshape(B, E)
+    assert (out.float().cpu() - ref).abs().max().item() <= 3e-2
+
+
 def attn_ref(q, k, v, key_mask, causal, scale):
     """q [B,Sq,H,hd] etc. float64 reference with the oracle's masking (finfo.min add)."""
     B, Sq, H, hd = q.shape
@@ -268,6 +295,8 @@ def attn_ref(q, k, v, key_mask, causal, scale):
     (2, 2, 1, 33, 64, True, True),       # decode step against a cache
     (1, 1, 9, 9, 160, False, False),
     (1, 4, 257, 257, 64, False, False),  # ViT-L/14
+    (1, 2, 577, 577, 64, False, False),  # ViT-L/14@336px: what the reference's stored embeddings use (base_env.jsonnet:39-40)
+    (1, 2, 577, 577, 64, False, True),   # ... with a ragged key mask (10 query / key tiles of 64, the last one 1 row deep)
     (2, 2, 70, 70, 96, True, True),      # mfma path, 3 k-steps
     (1, 2, 3, 200, 128, True, False),    # few queries against a long cache, two query-tile-free key tiles
     (2, 1, 100, 100, 80, False, True),
