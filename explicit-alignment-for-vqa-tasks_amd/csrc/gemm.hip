@@ -39,6 +39,7 @@ struct GemmParams {
     int M, N, K;
     int64_t lda, ldb, ldc, ld_aux, ldr;
     int act, out_f32;
+    int ablate;                    // eavqa_gemm_ex timing-only ablations of the specialised kernels (0 in the product path)
     float alpha;
     int tiles_m, tiles_n;
     int vec_c, vec_aux, vec_res, vec_bias;   // 16-byte (8-byte for bf16) vector access allowed on C / aux / residual / bias
@@ -1175,7 +1176,7 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     if (residual && ldr < N) return EAVQA_E_ARG;
 
     GemmParams p;
-    p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = nullptr;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = nullptr; p.ablate = kn.ablate;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
     p.act = act; p.out_f32 = out_f32; p.alpha = alpha;
     p.tiles_m = (M + BM - 1) / BM;
@@ -1279,7 +1280,7 @@ extern "C" int eavqa_gemm_fp8(int M, int N, int K, const void* A, int64_t lda, c
     if ((aux_in || aux_out) && ld_aux < N) return EAVQA_E_ARG;
     if (residual && ldr < N) return EAVQA_E_ARG;
     GemmParams p;
-    p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = a_row_scale;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = a_row_scale; p.ablate = 0;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
     p.act = act; p.out_f32 = out_f32; p.alpha = alpha * b_scale;
     p.tiles_m = (M + BM - 1) / BM;
