@@ -201,3 +201,41 @@ def test_an_undercounted_label_hint_poisons_the_loss():
     bad = T(z["labels"]).clone()
     bad[0, 0] = V + 5                                                      # a label beyond the vocabulary (torch asserts)
     assert torch.isnan(ex.model(**{**kw, "labels": bad}).loss).item()
+
+
+def test_fewshot_generation_from_a_module_parser_batch():
+    """The data path of BASELINE configs[3] end to end on the host side: `ModuleParser` few-shot modules (QInput + EmbeddingInput,
+    module_parser.py:68-93,234-260) -> collate -> `generate_fewshot` with the sentinel id that `register_special_tokens` returns;
+    ids equal the oracle's `insert_prefix_into_input` + greedy loop on the same batch (fp32, exact)."""
+    import json
+    from test_model_gpu import _oracle_fewshot_generate
+    from test_module_parser import build_word_tokenizer
+    from eavqa_amd.data.module_parser import VQA2Collator, make_sample, register_special_tokens
+    from eavqa_amd.models.clipcap import ClipCaptionPrefix
+    from eavqa_amd.models.lm import FrozenCausalLM, LMConfig, random_init_state_dict
+    from eavqa_amd.utils.attrdict import AttrDict
+    with open(os.path.join(GOLDEN, "module_parser.json")) as f:
+        gold = json.load(f)
+    case = next(c for c in gold["cases"] if c["name"] == "fewshot_2")
+    tok = build_word_tokenizer(gold["words"])
+    n_img = case["num_shots"] + 1
+    special = register_special_tokens(tok, case["special_tokens"], num_sentinels=n_img)
+    tok.pad_token = tok.eos_token
+    cfg = AttrDict(data_loader=AttrDict(additional=AttrDict(case["additional"])), model_config=AttrDict(case["module_cfg"]))
+    store = {k: torch.tensor(v) for k, v in gold["store"].items()}
+    batch = VQA2Collator(cfg, tok)([make_sample(it, gold["examples"], store, case["num_shots"]) for it in gold["items"]])
+    ids, mask, emb = batch["generative_input_ids"], batch["generative_attention_mask"], batch["clip_embeddings"]
+    B, D, L = ids.shape[0], emb.shape[-1], 3
+    assert tuple(emb.shape) == (B, n_img, 1, D)
+    lcfg = LMConfig("opt", 2, 4, 64, 96, len(tok), 200, 1e-5, "relu", tok.eos_token_id, tok.pad_token_id)
+    sd = random_init_state_dict(lcfg, 3, "cpu")
+    lm = FrozenCausalLM(lcfg, sd, torch.float32, DEV)
+    torch.manual_seed(1)
+    model = ClipCaptionPrefix(prefix_length=L, prefix_size=D, mapping_type="mlp", lm=lm, dtype=torch.float32, device=DEV).eval()
+    got = model.generate_fewshot(ids, emb, mask, num_shots=case["num_shots"], special_token_id=special, max_length=4,
+                                 pad_token_id=tok.pad_token_id, eos_token_id=None)
+    mapper = {k: v.detach().cpu() for k, v in model.clip_project.state_dict().items()}
+    ocfg = dict(arch="opt", n_layer=2, n_head=4, act="relu")
+    with torch.no_grad():
+        want = _oracle_fewshot_generate(sd, ocfg, mapper, L, ids, emb.reshape(B, n_img, D), mask, n_img, special, 4, tok.pad_token_id, None)
+    assert got == want

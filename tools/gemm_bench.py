@@ -18,6 +18,10 @@ SHAPES = [  # (M, N, K, what)
     (32, 7680, 2560, "decode qkv"), (32, 2560, 2560, "decode proj"), (32, 10240, 2560, "decode fc1"), (32, 2560, 10240, "decode fc2"),
     (32, 50272, 2560, "decode lm_head"), (64, 12800, 6400, "mlp fc2 fwd"),
     (1943, 1280, 64, "epi proj"), (1943, 3840, 64, "epi qkv"), (1943, 5120, 64, "epi fc1"), (1943, 1280, 3840, "packed da"),
+    (1943, 6144, 2048, "opt13 qkv"), (1943, 2048, 2048, "opt13 proj"), (1943, 8192, 2048, "opt13 fc1"), (1943, 2048, 8192, "opt13 fc2"),
+    (1943, 2048, 6144, "opt13 da"), (1303, 50272, 2048, "opt13 head"), (1303, 2048, 50304, "opt13 dhead"),
+    (16448, 3072, 1024, "vitL64 qkv"), (16448, 1024, 1024, "vitL64 proj"), (16448, 4096, 1024, "vitL64 fc1"), (16448, 1024, 4096, "vitL64 fc2"),
+    (2048, 12288, 4096, "opt67 qkv"), (2048, 4096, 4096, "opt67 proj"), (2048, 16384, 4096, "opt67 fc1"), (2048, 4096, 16384, "opt67 fc2"),
     (2688, 1280, 32, "fixed K=32"), (2688, 1280, 320, "fixed K=320"), (1943, 1280, 1280, "packed proj"), (1943, 3840, 1280, "packed qkv"),
     (1943, 5120, 1280, "packed fc1"), (1943, 1280, 5120, "packed fc2"),
     (2688, 3840, 1280, "qkv fwd"), (2688, 1280, 1280, "proj fwd / dctx"), (2688, 5120, 1280, "fc1 fwd / du"),
