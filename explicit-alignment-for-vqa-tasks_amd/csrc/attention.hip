@@ -611,12 +611,14 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
         return EAVQA_OK;
     }
     if (k_new || v_new) return EAVQA_E_SHAPE;          // the append form exists for the decode kernel only
-    if (dtype == EAVQA_BF16 && eavqa_attn_mfma::supported(hd) && !g_force_valu) {
+    const bool wide = eavqa_attn_mfma::supported_wide(hd, Sq, Sk) && !(ldq % 8 || ldk % 8 || ldv % 8);
+    if (dtype == EAVQA_BF16 && (eavqa_attn_mfma::supported(hd) || wide) && !g_force_valu) {
         eavqa_attn_mfma::Params m = {};
         m.q = q; m.k = k; m.v = v; m.out = o; m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo;
         m.key_mask = key_mask; m.ld_mask = p.ld_mask; m.cu = cu_seqlens; m.lse = lse;
         m.B = B; m.H = H; m.Sq = Sq; m.Sk = Sk; m.hd = hd; m.causal = causal; m.stat_ld = Sq;
         m.bsq = p.bsq; m.bsk = p.bsk; m.scale = scale;
+        if (wide) return eavqa_attn_mfma::run_wide(0, m, s);
         return eavqa_attn_mfma::run(0, m, s);
     }
     return dtype == EAVQA_F32 ? dispatch<float>(K_FWD, p, s) : dispatch<bf16_t>(K_FWD, p, s);
@@ -673,13 +675,15 @@ extern "C" int eavqa_attention_bwd_ex(int dtype, int B, int H, int Sq, int Sk, i
     p.bsq = Sq; p.bsk = Sk; p.ld_mask = Sk; p.cu = cu_seqlens; p.stat_ld = Sq;
     if (cu_seqlens && (key_mask || Sq != Sk)) return EAVQA_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == EAVQA_BF16 && eavqa_attn_mfma::supported(hd) && !g_force_valu) {
+    const bool wide = eavqa_attn_mfma::supported_wide(hd, Sq, Sk) && !(ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8);
+    if (dtype == EAVQA_BF16 && (eavqa_attn_mfma::supported(hd) || wide) && !g_force_valu) {
         eavqa_attn_mfma::Params m = {};
         m.q = q; m.k = k; m.v = v; m.o = o; m.d_o = d_o; m.dq = dq; m.dk = dk; m.dv = dv;
         m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo; m.lddo = lddo; m.lddq = lddq; m.lddk = lddk; m.lddv = lddv;
         m.key_mask = key_mask; m.ld_mask = Sk; m.cu = cu_seqlens; m.lse = const_cast<float*>(lse); m.delta = delta;
         m.B = B; m.H = H; m.Sq = Sq; m.Sk = Sk; m.hd = hd; m.causal = causal; m.stat_ld = Sq;
         m.bsq = Sq; m.bsk = Sk; m.scale = scale;
+        if (wide) return eavqa_attn_mfma::run_wide(3, m, s);
         if (Sq <= eavqa_attn_mfma::TILE && Sk <= eavqa_attn_mfma::TILE && !g_split_bwd) return eavqa_attn_mfma::run(3, m, s);
         rc = eavqa_attn_mfma::run(1, m, s);
         if (rc) return rc;

@@ -1,6 +1,7 @@
 // bf16 attention forward / backward on the matrix cores (v_mfma_f32_16x16x32_bf16), head dims 64 / 80 /
-// 96 / 128.  Called from eavqa_attention_fwd / _bwd (attention.hip) for dtype bf16; the fp32 path and the
-// other head dims stay on the vector-ALU kernels.
+// 96 / 128, and any wider head dim (multiple of 8) when the problem is one 64 x 64 tile (the mapping network: see the
+// "wide heads" section at the end).  Called from eavqa_attention_fwd / _bwd (attention.hip) for dtype bf16; the fp32 path
+// and the other head dims stay on the vector-ALU kernels.
 //
 // One workgroup = 4 waves = 64 "lane items" of one (batch, head); a wave owns 16 of them, ONE PER LANE
 // COLUMN (lane & 15), and streams the other sequence dimension ("register items") through LDS in tiles
@@ -537,6 +538,248 @@ int run(int which, const Params& p, hipStream_t s) {
         case 128: return launch<4, 8>(which, p, s);
         default: return EAVQA_E_SHAPE;
     }
+}
+
+// ------------------------------------------------------------------------------------ wide heads, one tile
+// The transformer mapping network (reference: src/models/clip_cap.py Transformer / MultiHeadAttention: 8 heads over
+// dim_embedding = the LM width) has head dims 160 (GPT-2-large) .. 512 (OPT-6.7B) over clip_length + prefix_length <= 64
+// positions.  The whole (batch, head) problem is one 64 x 64 score tile, so the head dim is walked in CHUNKS of 128 with the
+// geometry of the hd = 128 kernels: S (and dP) accumulate over the chunks, O / dQ / dK / dV are produced chunk by chunk, and no
+// online-softmax rescaling exists because there is only one key tile.
+constexpr int WKS = 4, WD16 = 8, WCH = 128;
+
+template <int KS>
+__device__ __forceinline__ void tile_dot_acc(f32x4 (&acc)[4], const char* rowmaj, const bf16x8 (&bf)[KS], int x, int g) {
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowmaj + (16 * f + x) * Geo<KS>::PR + (32 * s + 8 * g) * 2);
+            acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[s], acc[f], 0, 0, 0);
+        }
+}
+
+__global__ __launch_bounds__(256) void fwd_wide_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + Geo<WKS>::ROW_BYTES;
+    int* valid = reinterpret_cast<int*>(Vs + Geo<WKS>::ROW_BYTES);
+
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    if (!window(p, b, 0, true)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const int qi = wave * 16 + x;
+    const bool active = qi < p.Sq;
+    const int off = p.Sk - p.Sq, head_off = h * p.hd;
+    const int nch = (p.hd + WCH - 1) / WCH;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + p.bsq * p.ldq;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + p.bsk * p.ldk;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + p.bsk * p.ldv;
+
+    for (int c = threadIdx.x; c < TILE; c += 256)
+        valid[c] = (c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + c] != 0);
+    f32x4 st[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) st[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nch; ++c) {
+        const int hc = min(WCH, p.hd - c * WCH), ho = head_off + c * WCH;
+        char* buf = (c & 1) ? Vs : Ks;                       // alternate images: chunk c + 1 is staged while chunk c is consumed
+        stage<WKS>(buf, nullptr, K, p.ldk, 0, p.Sk, hc, ho);
+        bf16x8 qf[WKS];
+        load_bfrag<WKS>(qf, Q, p.ldq, qi, active, hc, ho, g);
+        __syncthreads();
+        tile_dot_acc<WKS>(st, buf, qf, x, g);
+    }
+    float tmax = -FLT_MAX;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int kk = 16 * f + 4 * g + r;
+            const bool exists = kk < p.Sk;
+            const bool vis = valid[kk] && (!p.causal || kk <= qi + off);
+            st[f][r] = exists ? (vis ? st[f][r] * p.scale : -FLT_MAX) : -INFINITY;
+            tmax = fmaxf(tmax, st[f][r]);
+        }
+    const float m = group4_max(tmax);
+    float lsum = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pj = __expf(st[f][r] - m);
+            st[f][r] = pj;
+            lsum += pj;
+        }
+    const float l = group4_sum(lsum);
+    const float inv = 1.f / l;
+    bf16_t* O = reinterpret_cast<bf16_t*>(p.out) + p.bsq * p.ldo;
+    for (int c = 0; c < nch; ++c) {
+        const int hc = min(WCH, p.hd - c * WCH), ho = head_off + c * WCH;
+        char* buf = ((c + nch) & 1) ? Vs : Ks;
+        __syncthreads();                                     // two chunks back is consumed: its image may be overwritten
+        stage<WKS>(buf, nullptr, V, p.ldv, 0, p.Sk, hc, ho);
+        __syncthreads();
+        f32x4 acc[WD16];
+#pragma unroll
+        for (int dm = 0; dm < WD16; ++dm) acc[dm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        tile_accumulate<WKS, WD16>(acc, buf, st, x, g);
+        if (active) {
+#pragma unroll
+            for (int dm = 0; dm < WD16; ++dm) store4(O, p.ldo, qi, ho, 16 * dm + 4 * g, hc, acc[dm], inv);
+        }
+    }
+    if (active && p.lse && g == 0) p.lse[((int64_t)b * p.H + h) * p.stat_ld + qi] = m + __logf(l);
+}
+
+__global__ __launch_bounds__(256) void bwd_wide_kernel(Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* DOs = Qs + Geo<WKS>::ROW_BYTES;
+    char* Ks = DOs + Geo<WKS>::ROW_BYTES;
+    char* DSs = Ks + Geo<WKS>::ROW_BYTES;                                 // [64 queries][64 keys] bf16, pitch DS_PITCH
+    constexpr int DS_PITCH = TILE * 2 + 16;
+    float* stats = reinterpret_cast<float*>(DSs + TILE * DS_PITCH);       // lse[64], delta[64]
+
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    if (!window(p, b, 0, false)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const int item = wave * 16 + x;                   // this lane's key (P, dS, dV, dK) and query (delta, dQ)
+    const int off = p.Sk - p.Sq, head_off = h * p.hd;
+    const int nch = (p.hd + WCH - 1) / WCH;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + p.bsq * p.ldq;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + p.bsk * p.ldk;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + p.bsk * p.ldv;
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(p.o) + p.bsq * p.ldo;
+    const bf16_t* DO = reinterpret_cast<const bf16_t*>(p.d_o) + p.bsq * p.lddo;
+    const bool qa = item < p.Sq, kactive = item < p.Sk;
+    const int64_t stat_at = ((int64_t)b * p.H + h) * p.stat_ld + item;
+    const bool kvalid = kactive && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + item] != 0);
+
+    // ---- pass 1 over the chunks: delta = rowsum(dO * O) of query `item`; S and dP of key `item` against all queries
+    f32x4 sc[4], dp[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { sc[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    float dsum = 0.f;
+    for (int c = 0; c < nch; ++c) {
+        const int hc = min(WCH, p.hd - c * WCH), ho = head_off + c * WCH;
+        __syncthreads();
+        stage<WKS>(Qs, nullptr, Q, p.ldq, 0, p.Sq, hc, ho);
+        stage<WKS>(DOs, nullptr, DO, p.lddo, 0, p.Sq, hc, ho);
+        bf16x8 kf[WKS], vf[WKS], of[WKS];
+        load_bfrag<WKS>(kf, K, p.ldk, item, kactive, hc, ho, g);
+        load_bfrag<WKS>(vf, V, p.ldv, item, kactive, hc, ho, g);
+        load_bfrag<WKS>(of, O, p.ldo, item, qa, hc, ho, g);
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < WKS; ++s) {
+            const bf16x8 dof = *reinterpret_cast<const bf16x8*>(DOs + item * Geo<WKS>::PR + (32 * s + 8 * g) * 2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dsum += (float)dof[j] * (float)of[s][j];
+        }
+        tile_dot_acc<WKS>(sc, Qs, kf, x, g);
+        tile_dot_acc<WKS>(dp, DOs, vf, x, g);
+    }
+    {
+        const float delta = group4_sum(dsum);
+        if (g == 0) {
+            stats[item] = qa ? p.lse[stat_at] : 0.f;
+            stats[TILE + item] = qa ? delta : 0.f;
+            if (qa) p.delta[stat_at] = delta;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = 16 * f + 4 * g + r;
+            const bool exists = qq < p.Sq;
+            const bool vis = exists && kvalid && (!p.causal || item <= qq + off);
+            const float pj = exists ? __expf((vis ? sc[f][r] * p.scale : -FLT_MAX) - stats[qq]) : 0.f;
+            sc[f][r] = pj;                                                   // P
+            dp[f][r] = pj * (dp[f][r] - stats[TILE + qq]) * p.scale;        // dS
+            *reinterpret_cast<bf16_t*>(DSs + qq * DS_PITCH + item * 2) = (bf16_t)(kactive ? dp[f][r] : 0.f);
+        }
+    bf16x8 dsf[2];                                    // B fragments of dQ^T += K^T . dS^T: 8 consecutive keys of query `item`
+    __syncthreads();                                  // the dS image is complete
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) dsf[s2] = *reinterpret_cast<const bf16x8*>(DSs + item * DS_PITCH + (32 * s2 + 8 * g) * 2);
+
+    // ---- pass 2 over the chunks: dV, dK of key `item`, dQ of query `item`
+    bf16_t* DK = reinterpret_cast<bf16_t*>(p.dk) + p.bsk * p.lddk;
+    bf16_t* DV = reinterpret_cast<bf16_t*>(p.dv) + p.bsk * p.lddv;
+    bf16_t* DQ = reinterpret_cast<bf16_t*>(p.dq) + p.bsq * p.lddq;
+    for (int c = nch - 1; c >= 0; --c) {              // the last chunk of pass 1 is still staged in Qs / DOs
+        const int hc = min(WCH, p.hd - c * WCH), ho = head_off + c * WCH;
+        if (c != nch - 1) {
+            __syncthreads();
+            stage<WKS>(Qs, nullptr, Q, p.ldq, 0, p.Sq, hc, ho);
+            stage<WKS>(DOs, nullptr, DO, p.lddo, 0, p.Sq, hc, ho);
+        }
+        stage<WKS>(Ks, nullptr, K, p.ldk, 0, p.Sk, hc, ho);
+        __syncthreads();
+        {
+            f32x4 dv[WD16];
+#pragma unroll
+            for (int dm = 0; dm < WD16; ++dm) dv[dm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            tile_accumulate<WKS, WD16>(dv, DOs, sc, x, g);
+            if (kactive) {
+#pragma unroll
+                for (int dm = 0; dm < WD16; ++dm) store4(DV, p.lddv, item, ho, 16 * dm + 4 * g, hc, dv[dm], 1.f);
+            }
+        }
+        {
+            f32x4 dk[WD16];
+#pragma unroll
+            for (int dm = 0; dm < WD16; ++dm) dk[dm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            tile_accumulate<WKS, WD16>(dk, Qs, dp, x, g);
+            if (kactive) {
+#pragma unroll
+                for (int dm = 0; dm < WD16; ++dm) store4(DK, p.lddk, item, ho, 16 * dm + 4 * g, hc, dk[dm], 1.f);
+            }
+        }
+        {
+            f32x4 dq[WD16];
+#pragma unroll
+            for (int dm = 0; dm < WD16; ++dm) dq[dm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int q = x >> 2, pp = x & 3;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* row_lo = Ks + (32 * s2 + 8 * g + q) * Geo<WKS>::PR + 8 * pp;     // keys 32 s2 + 8 g .. +3
+                const char* row_hi = row_lo + 4 * Geo<WKS>::PR;                                // keys .. +4 .. +7
+#pragma unroll
+                for (int dm = 0; dm < WD16; ++dm) {
+                    const bf16x4 lo = lds_tr4(row_lo + 32 * dm);
+                    const bf16x4 hi = lds_tr4(row_hi + 32 * dm);
+                    bf16x8 a;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
+                    dq[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, dsf[s2], dq[dm], 0, 0, 0);
+                }
+            }
+            if (qa) {
+#pragma unroll
+                for (int dm = 0; dm < WD16; ++dm) store4(DQ, p.lddq, item, ho, 16 * dm + 4 * g, hc, dq[dm], 1.f);
+            }
+        }
+    }
+}
+
+bool supported_wide(int hd, int Sq, int Sk) { return hd > 128 && hd % 8 == 0 && Sq <= TILE && Sk <= TILE; }
+
+// which: 0 forward, 3 all three gradients
+int run_wide(int which, const Params& p, hipStream_t s) {
+    const size_t row = Geo<WKS>::ROW_BYTES;
+    if (which == 0) {
+        hipLaunchKernelGGL(fwd_wide_kernel, dim3(1, p.B * p.H), dim3(256), 2 * row + TILE * 4, s, p);
+    } else if (which == 3) {
+        hipLaunchKernelGGL(bwd_wide_kernel, dim3(1, p.B * p.H), dim3(256), 3 * row + TILE * (TILE * 2 + 16) + 2 * TILE * 4, s, p);
+    } else {
+        return EAVQA_E_ARG;
+    }
+    if (hipGetLastError() != hipSuccess) return EAVQA_E_LAUNCH;
+    return EAVQA_OK;
 }
 
 }  // namespace eavqa_attn_mfma

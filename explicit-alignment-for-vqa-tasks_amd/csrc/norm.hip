@@ -90,18 +90,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int x_f32, int rows, int co
             float4 d = elem<T>::ld4(dy + (int64_t)row * lddy + 4 * c);
             float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
             xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-            if (dgamma) {
-                atomicAdd(dgamma + 4 * c + 0, d.x * xh[i].x);
-                atomicAdd(dgamma + 4 * c + 1, d.y * xh[i].y);
-                atomicAdd(dgamma + 4 * c + 2, d.z * xh[i].z);
-                atomicAdd(dgamma + 4 * c + 3, d.w * xh[i].w);
-            }
-            if (dbeta) {
-                atomicAdd(dbeta + 4 * c + 0, d.x);
-                atomicAdd(dbeta + 4 * c + 1, d.y);
-                atomicAdd(dbeta + 4 * c + 2, d.z);
-                atomicAdd(dbeta + 4 * c + 3, d.w);
-            }
             gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
             s1 += (gd[i].x + gd[i].y) + (gd[i].z + gd[i].w);
             s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
@@ -126,6 +114,37 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int x_f32, int rows, int co
             *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + 4 * c) = o;
             if (dx_lowp) elem<T>::st4(dx_lowp + (int64_t)row * ld_lowp + 4 * c, o);
         }
+    }
+}
+
+// dgamma[c] += sum_r dy[r,c] * xhat[r,c], dbeta[c] += sum_r dy[r,c] (the mapper's LayerNorms only: the LM is frozen).  A block owns 64
+// columns x 64 rows, sums them in registers / LDS and issues ONE atomic per column: rows / 64 atomics per column instead of one per
+// element (2 048 x 4 096 elements cost 440-540 us through the atomic units, MI355X_MICROARCH.md "Global float atomics").
+template <typename T>
+__global__ __launch_bounds__(256) void ln_dparam_kernel(int x_f32, int rows, int cols, const void* x, int64_t ldx, const T* dy, int64_t lddy,
+                                                        const float* mean, const float* rstd, float* dgamma, float* dbeta) {
+    __shared__ float sg[4][64], sb[4][64];
+    const int tid = threadIdx.x, cl = tid & 63, rs = tid >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    float g = 0.f, b = 0.f;
+    if (col < cols) {
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int row = blockIdx.y * 64 + rs + 4 * i;
+            if (row < rows) {
+                const int64_t off = (int64_t)row * ldx + col;
+                const float xv = x_f32 ? reinterpret_cast<const float*>(x)[off] : elem<T>::ld(reinterpret_cast<const T*>(x) + off);
+                const float d = elem<T>::ld(dy + (int64_t)row * lddy + col);
+                g += d * (xv - mean[row]) * rstd[row];
+                b += d;
+            }
+        }
+    }
+    sg[rs][cl] = g; sb[rs][cl] = b;
+    __syncthreads();
+    if (tid < 64 && col < cols) {
+        if (dgamma) atomicAdd(dgamma + col, (sg[0][cl] + sg[1][cl]) + (sg[2][cl] + sg[3][cl]));
+        if (dbeta) atomicAdd(dbeta + col, (sb[0][cl] + sb[1][cl]) + (sb[2][cl] + sb[3][cl]));
     }
 }
 
@@ -163,6 +182,9 @@ int ln_bwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, c
     else if (nv <= 16) EAVQA_LN_BWD(16);
     else return EAVQA_E_SHAPE;  // 2 x 32 float4 per lane would spill; cols <= 4096 in backward
 #undef EAVQA_LN_BWD
+    if (dgamma || dbeta)
+        hipLaunchKernelGGL((ln_dparam_kernel<T>), dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, x_f32, rows, cols, x, ldx,
+                           reinterpret_cast<const T*>(dy), lddy, mean, rstd, dgamma, dbeta);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }

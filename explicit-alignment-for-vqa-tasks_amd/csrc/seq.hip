@@ -149,19 +149,31 @@ __global__ __launch_bounds__(64) void labels_kernel(int mode, int T, int L, cons
     }
 }
 
+// One thread per PIXEL (reads fully coalesced along x; a patch row of ps pixels lands contiguously in its patch): the round-1 kernel
+// walked the patch's columns and gathered single floats, 2.3 ms for 32 images at patch 14 (ViT-L/14).
 template <typename T>
-__global__ __launch_bounds__(256) void patchify_kernel(int img, int ps, int g, const float* px, T* out, int64_t ldp) {
-    const int row = blockIdx.x;                // b*g*g + gy*g + gx
-    const int b = row / (g * g), cell = row - b * g * g, gy = cell / g, gx = cell - gy * g;
-    const int kreal = 3 * ps * ps;
-    for (int c = threadIdx.x; c < ldp; c += 256) {
-        float v = 0.f;
-        if (c < kreal) {
-            const int ch = c / (ps * ps), rem = c - ch * ps * ps, i = rem / ps, j = rem - i * ps;
-            v = px[(((int64_t)b * 3 + ch) * img + gy * ps + i) * img + gx * ps + j];
-        }
-        elem<T>::st(out + (int64_t)row * ldp + c, v);
-    }
+__global__ __launch_bounds__(256) void patchify_kernel(int64_t total, int img, int ps, int g, const float* __restrict__ px, T* __restrict__ out,
+                                                       int64_t ldp) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int x = (int)(idx % img);
+    const int64_t t = idx / img;
+    const int y = (int)(t % img);
+    const int64_t t2 = t / img;
+    const int ch = (int)(t2 % 3), b = (int)(t2 / 3);
+    const int gy = y / ps, gx = x / ps;
+    if (gy >= g || gx >= g) return;                              // pixels beyond the last whole patch (img % ps != 0)
+    const int64_t row = ((int64_t)b * g + gy) * g + gx;
+    const int col = (ch * ps + (y - gy * ps)) * ps + (x - gx * ps);
+    elem<T>::st(out + row * ldp + col, px[idx]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void zero_cols_kernel(int64_t rows, int c0, int c1, T* out, int64_t ldp) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int w = c1 - c0;
+    if (idx >= rows * w) return;
+    elem<T>::st(out + (idx / w) * ldp + c0 + (int)(idx % w), 0.f);
 }
 
 template <typename T>
@@ -475,11 +487,16 @@ extern "C" int eavqa_patchify(int dtype, int B, int img, int ps, const float* pi
     if (ldp < 3 * ps * ps) return EAVQA_E_ARG;
     const int g = img / ps;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == EAVQA_F32)
-        hipLaunchKernelGGL(patchify_kernel<float>, dim3(B * g * g), dim3(256), 0, s, img, ps, g, pixels, (float*)patches, ldp);
-    else if (dtype == EAVQA_BF16)
-        hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(B * g * g), dim3(256), 0, s, img, ps, g, pixels, (bf16_t*)patches, ldp);
-    else return EAVQA_E_DTYPE;
+    const int64_t total = (int64_t)B * 3 * img * img, rows = (int64_t)B * g * g;
+    const int kreal = 3 * ps * ps;
+    const unsigned blocks = (unsigned)((total + 255) / 256), zblocks = (unsigned)((rows * (ldp - kreal) + 255) / 256);
+    if (dtype == EAVQA_F32) {
+        hipLaunchKernelGGL(patchify_kernel<float>, dim3(blocks), dim3(256), 0, s, total, img, ps, g, pixels, (float*)patches, ldp);
+        if (ldp > kreal) hipLaunchKernelGGL(zero_cols_kernel<float>, dim3(zblocks), dim3(256), 0, s, rows, kreal, (int)ldp, (float*)patches, ldp);
+    } else if (dtype == EAVQA_BF16) {
+        hipLaunchKernelGGL(patchify_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, total, img, ps, g, pixels, (bf16_t*)patches, ldp);
+        if (ldp > kreal) hipLaunchKernelGGL(zero_cols_kernel<bf16_t>, dim3(zblocks), dim3(256), 0, s, rows, kreal, (int)ldp, (bf16_t*)patches, ldp);
+    } else return EAVQA_E_DTYPE;
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }
@@ -516,3 +533,4 @@ extern "C" int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }
+

@@ -225,8 +225,9 @@ def test_fewshot_generation_from_a_module_parser_batch():
     store = {k: torch.tensor(v) for k, v in gold["store"].items()}
     batch = VQA2Collator(cfg, tok)([make_sample(it, gold["examples"], store, case["num_shots"]) for it in gold["items"]])
     ids, mask, emb = batch["generative_input_ids"], batch["generative_attention_mask"], batch["clip_embeddings"]
+    assert tuple(emb.shape) == (ids.shape[0], n_img, 1, 6)
+    emb = torch.nn.functional.pad(emb, (0, 2))            # the fixture's 6-d toy embeddings -> 8 (GEMM operands need K % 4 == 0)
     B, D, L = ids.shape[0], emb.shape[-1], 3
-    assert tuple(emb.shape) == (B, n_img, 1, D)
     lcfg = LMConfig("opt", 2, 4, 64, 96, len(tok), 200, 1e-5, "relu", tok.eos_token_id, tok.pad_token_id)
     sd = random_init_state_dict(lcfg, 3, "cpu")
     lm = FrozenCausalLM(lcfg, sd, torch.float32, DEV)

@@ -300,6 +300,10 @@ def attn_ref(q, k, v, key_mask, causal, scale):
     (2, 2, 70, 70, 96, True, True),      # mfma path, 3 k-steps
     (1, 2, 3, 200, 128, True, False),    # few queries against a long cache, two query-tile-free key tiles
     (2, 1, 100, 100, 80, False, True),
+    (2, 8, 64, 64, 512, False, False),   # transformer mapper on OPT-6.7B (cfg5): 4096 / 8 heads, clip_length + prefix_length = 64
+    (2, 8, 20, 20, 160, False, False),   # transformer mapper on GPT-2-large: 1280 / 8 heads (wide-head one-tile kernels, 2 chunks)
+    (1, 2, 37, 37, 256, True, True),     # wide heads, causal + key mask
+    (1, 2, 33, 64, 320, True, False),    # wide heads, Sq < Sk
 ])
 def test_attention_forward_backward(ops, attn_path, dtype, B, H, Sq, Sk, hd, causal, masked):
     E = H * hd
@@ -327,6 +331,23 @@ def test_attention_forward_backward(ops, attn_path, dtype, B, H, Sq, Sk, hd, cau
     tb = 5e-5 if dtype == torch.float32 else 6e-2
     for got, want in ((dq, qq.grad), (dk, kk.grad), (dv, vv.grad)):
         assert (got.float().cpu().reshape(want.shape) - want.float()).abs().max().item() <= tb * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,S,hd", [(2, 2, 42, 200), (1, 3, 64, 640), (2, 1, 5, 136)])
+def test_attention_wide_heads_ragged_chunk_bf16(ops, B, H, S, hd):
+    """Head dims the vector-ALU kernels do not cover (GPT-2-xl mapper 1600 / 8 = 200, OPT-13B 5120 / 8 = 640): bf16 only, the last
+    128-wide chunk of the head dim partly empty."""
+    E = H * hd
+    q, k, v, do = (rnd(B, S, H, hd, dtype=torch.bfloat16, seed=i) for i in (1, 2, 3, 4))
+    qq, kk, vv = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    ref = attn_ref(qq, kk, vv, None, False, hd ** -0.5)
+    ref.backward(do.double())
+    Q, K, V = (t.reshape(B * S, E).to(DEV) for t in (q, k, v))
+    o, lse = ops.attention_fwd(Q, K, V, B, H, S, S, hd, causal=False, scale=hd ** -0.5, save_lse=True)
+    assert (o.float().cpu().reshape(B, S, H, hd) - ref.detach().float()).abs().max().item() <= 2e-2
+    dq, dk, dv = ops.attention_bwd(Q, K, V, o, do.reshape(B * S, E).to(DEV), lse, B, H, S, S, hd, causal=False, scale=hd ** -0.5)
+    for got, want in ((dq, qq.grad), (dk, kk.grad), (dv, vv.grad)):
+        assert (got.float().cpu().reshape(want.shape) - want.float()).abs().max().item() <= 6e-2 * max(1.0, want.abs().max().item())
 
 
 def test_attention_fully_masked_row_is_finite(ops):
