@@ -28,6 +28,7 @@ SIGNATURES = {
     "eavqa_layernorm_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, ptr],
     "eavqa_attention_fwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i64, ptr, i32, f32, ptr, ptr],
     "eavqa_attention_decode": [i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i64, ptr, ptr, i64, ptr, i64, ptr, i64, f32, ptr],
+    "eavqa_attention_decode_splitk": [i32, i32, i32, i32, i32, ptr, i32, ptr, ptr, i64, ptr, i64, i64, ptr, i64, ptr, i64, f32, ptr],
     "eavqa_attention_bwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64,
                             ptr, i64, ptr, i64, ptr, i64, ptr, ptr, i32, f32, ptr, ptr, ptr],
     "eavqa_build_prefix_rows": [i32, i32, i32, ptr, ptr, i32, i32, i32, ptr, ptr, ptr, ptr],
@@ -71,6 +72,7 @@ SIGNATURES["eavqa_lm_block_forward"] = [i32, i32, C.POINTER(LMLayer), i32, i32, 
 SIGNATURES["eavqa_gemm_ex"] = SIGNATURES["eavqa_gemm"] + [i32]
 SIGNATURES["eavqa_attention_fwd_ex"] = SIGNATURES["eavqa_attention_fwd"] + [i32]
 SIGNATURES["eavqa_attention_bwd_ex"] = SIGNATURES["eavqa_attention_bwd"] + [i32]
+SIGNATURES["eavqa_gemm_splitk_ex"] = SIGNATURES["eavqa_gemm_splitk"] + [i32]
 
 _RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_lm_block_workspace_bytes": C.c_int64}
 

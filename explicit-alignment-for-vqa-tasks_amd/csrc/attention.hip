@@ -425,21 +425,31 @@ int check_common(int dtype, int B, int H, int Sq, int Sk, int hd) {
 // to LDS; every wave of a head reduces max / sum over all of them itself (no second exchange); the partial outputs of the
 // DEC_WPH waves are summed through LDS in wave order.  Same masking rule as the tiled kernels: masked scores become
 // -FLT_MAX (a fully masked row averages all keys).
-constexpr int DEC_U = 10;
-
-// DEC_WPH: 4 when the grid fits the chip once (one 16-wave workgroup per CU), fewer for larger batches, where several
-// smaller workgroups per CU overlap their latency chains instead
-template <int LPK, int DEC_WPH>
+// DEC_WPH: 4 when the grid fits the chip once (one 16-wave workgroup per CU), fewer for larger batches, where several smaller
+// workgroups per CU overlap their latency chains instead.
+// VLDS: V does not depend on the scores, so its bytes should be on their way while K is being scored - but a second batch of loads
+// held in registers does not fit a 16-wave workgroup's 128 VGPRs (measured: 41 spilled registers, 26.5 us against 18 us).  So the
+// whole V slice of the workgroup ([Sk keys][4 heads x hd], 100 KiB at Sk = 160, hd = 80) is fetched by LDS-DMA at the very start,
+// costs no registers, and P.V reads it from LDS: the kernel is ONE HBM round trip.  Taken when the image fits (<= 128 KiB) and
+// the grid is one workgroup per CU.
+template <int LPK, int DEC_WPH, int DEC_U, bool VLDS>
 __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                           int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv, bf16_t* __restrict__ out,
                                                           int64_t ldo, int64_t bsq, int64_t bsk, const int32_t* __restrict__ key_mask,
                                                           int64_t ld_mask, float* __restrict__ lse, int H, int Sk, int hd, float scale,
-                                                          const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new, int64_t ld_new) {
+                                                          const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new, int64_t ld_new,
+                                                          const float* __restrict__ qkv_part, int ks, const float* __restrict__ qkv_bias) {
     // k_new / v_new (eavqa_attention_decode): the K / V rows of the NEW position (key Sk - 1) still sit in the QKV projection's
     // output; the lanes that own that key take them from there and append them to the cache on the way (each 16-byte piece of a
     // cache row has exactly one owner lane), which saves the separate append pass of the decode step.
-    extern __shared__ float dec_sc[];                 // [4 heads][Sk] scores, then [4][DEC_WPH][128] partial outputs
+    // qkv_part (eavqa_attention_decode_splitk): q and the new K / V rows do not exist yet - the QKV projection left `ks` fp32 partial
+    // sums [ks][B][3 E]; every lane adds up the 8 values it needs (slices in index order, then the bias, then rounded to bf16: exactly
+    // what eavqa_splitk_finish would have stored), which also saves the finish pass.
+    extern __shared__ float dec_sc[];                 // [4 heads][Sk] scores, then [4][DEC_WPH][128] partial outputs, then the V image
     constexpr int KPI = 64 / LPK;
+    char* vimg = reinterpret_cast<char*>(dec_sc + 4 * Sk + 4 * DEC_WPH * 128);      // VLDS: [Sk][4 heads x hd] bf16
+    const int cpk = hd >> 1;                          // 16-byte pieces per key in the image (4 heads x hd / 8)
+    const bool appended = qkv_part || k_new;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = wave / DEC_WPH, part = wave % DEC_WPH;
     const int b = blockIdx.x, h = blockIdx.y * 4 + hh;
@@ -448,45 +458,112 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
     const bool active = head_ok && 8 * dl < hd;
     float* sc = dec_sc + hh * Sk;
     float* opart = dec_sc + 4 * Sk + (hh * DEC_WPH + part) * 128;
+    constexpr int STEP = KPI * DEC_WPH * DEC_U;
+    const int E3 = 3 * H * hd;
+    // bf16(sum_s P[s][b][col .. col+7] + bias[col ..]) - the value eavqa_splitk_finish stores
+    auto from_part = [&](int col) -> bf16x8 {
+        const float* p0 = qkv_part + (int64_t)b * E3 + col;
+        const int64_t slice = (int64_t)gridDim.x * E3;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        for (int s0 = 0; s0 < ks; s0 += 4) {              // four slices' loads in flight, added in index order
+            float4 ta[4], tc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float* ps = p0 + min(s0 + i, ks - 1) * slice;
+                ta[i] = *reinterpret_cast<const float4*>(ps);
+                tc[i] = *reinterpret_cast<const float4*>(ps + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (s0 + i == 0) { a = ta[0]; c = tc[0]; }
+                else if (s0 + i < ks) {
+                    a.x += ta[i].x; a.y += ta[i].y; a.z += ta[i].z; a.w += ta[i].w;
+                    c.x += tc[i].x; c.y += tc[i].y; c.z += tc[i].z; c.w += tc[i].w;
+                }
+            }
+        }
+        if (qkv_bias) {
+            const float4 a2 = *reinterpret_cast<const float4*>(qkv_bias + col), c2 = *reinterpret_cast<const float4*>(qkv_bias + col + 4);
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w; c.x += c2.x; c.y += c2.y; c.z += c2.z; c.w += c2.w;
+        }
+        bf16x8 r;
+        r[0] = (bf16_t)a.x; r[1] = (bf16_t)a.y; r[2] = (bf16_t)a.z; r[3] = (bf16_t)a.w;
+        r[4] = (bf16_t)c.x; r[5] = (bf16_t)c.y; r[6] = (bf16_t)c.z; r[7] = (bf16_t)c.w;
+        return r;
+    };
+    const bf16_t* kb = k + (int64_t)b * bsk * ldk + h * hd + 8 * dl;
+    const bf16_t* vb = v + (int64_t)b * bsk * ldv + h * hd + 8 * dl;
+    if (VLDS) {
+        const int n_keys = appended ? Sk - 1 : Sk;    // the new key's row is not in the cache yet: its owner lanes write the image
+        const int total = n_keys * cpk;
+        const int valid_pieces = min(cpk, ((H - blockIdx.y * 4) * hd) >> 3);      // a last group of < 4 heads: stay inside the row
+        const bf16_t* vsrc = v + (int64_t)b * bsk * ldv + blockIdx.y * 4 * hd;
+        for (int base = __builtin_amdgcn_readfirstlane(wave) * 64; base < total; base += 64 * 4 * DEC_WPH) {
+            const int c = base + lane;
+            const int key = c / cpk, piece = c - key * cpk;
+            if (c < total && piece < valid_pieces)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + (int64_t)key * ldv + piece * 8),
+                                                 (__attribute__((address_space(3))) void*)(vimg + base * 16), 16, 0, 0);
+        }
+    }
+    // key of (batch start j0, slot u): groups of KPI keys are dealt round-robin to the DEC_WPH waves of the head
+    auto key_of = [&](int j0, int u) { return j0 + (u * DEC_WPH + part) * KPI + sub; };
+    // the first batch of K goes out before anything that has to wait for the previous kernel's results (q and the new K / V row
+    // below): those L2 round trips then run under the HBM round trip instead of in front of it
+    bf16x8 kv0[DEC_U];
+#pragma unroll
+    for (int u = 0; u < DEC_U; ++u) {
+        const int j = key_of(0, u);
+        kv0[u] = (bf16x8){};
+        if (active && j < Sk) kv0[u] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)j * ldk);    // row Sk-1 may be stale: patched below
+    }
+    // the new position: its one owner lane per 16-byte piece fetches (or sums up) the row and appends it to the cache
+    bf16x8 knew = {}, vnew = {};
+    bool own_new = false;
+    if (qkv_part || k_new) {
+        const int rem = (Sk - 1) % STEP, grp = rem / KPI;
+        own_new = active && (rem % KPI) == sub && (grp % DEC_WPH) == part;
+        if (own_new) {
+            if (qkv_part) {
+                knew = from_part(H * hd + h * hd + 8 * dl);
+                vnew = from_part(2 * H * hd + h * hd + 8 * dl);
+            } else {
+                knew = *reinterpret_cast<const bf16x8*>(k_new + (int64_t)b * ld_new + h * hd + 8 * dl);
+                vnew = *reinterpret_cast<const bf16x8*>(v_new + (int64_t)b * ld_new + h * hd + 8 * dl);
+            }
+            *reinterpret_cast<bf16x8*>(const_cast<bf16_t*>(kb) + (int64_t)(Sk - 1) * ldk) = knew;
+            *reinterpret_cast<bf16x8*>(const_cast<bf16_t*>(vb) + (int64_t)(Sk - 1) * ldv) = vnew;
+            if (VLDS) *reinterpret_cast<bf16x8*>(vimg + ((Sk - 1) * cpk + hh * (hd >> 3) + dl) * 16) = vnew;
+        }
+    }
     float qf[8];
     {
         bf16x8 t = {};
-        if (active) t = *reinterpret_cast<const bf16x8*>(q + (int64_t)b * bsq * ldq + h * hd + 8 * dl);
+        if (active) t = qkv_part ? from_part(h * hd + 8 * dl) : *reinterpret_cast<const bf16x8*>(q + (int64_t)b * bsq * ldq + h * hd + 8 * dl);
 #pragma unroll
         for (int e = 0; e < 8; ++e) qf[e] = (float)t[e];
     }
-    const bf16_t* kb = k + (int64_t)b * bsk * ldk + h * hd + 8 * dl;
-    const bf16_t* vb = v + (int64_t)b * bsk * ldv + h * hd + 8 * dl;
-    const bf16_t* kn = k_new ? k_new + (int64_t)b * ld_new + h * hd + 8 * dl : nullptr;
-    const bf16_t* vn = v_new ? v_new + (int64_t)b * ld_new + h * hd + 8 * dl : nullptr;
     auto load_k = [&](int j) -> bf16x8 {
-        if (kn && j == Sk - 1) {
-            const bf16x8 t = *reinterpret_cast<const bf16x8*>(kn);
-            *reinterpret_cast<bf16x8*>(const_cast<bf16_t*>(kb) + (int64_t)j * ldk) = t;
-            return t;
-        }
+        if (own_new && j == Sk - 1) return knew;
         return *reinterpret_cast<const bf16x8*>(kb + (int64_t)j * ldk);
     };
     auto load_v = [&](int j) -> bf16x8 {
-        if (vn && j == Sk - 1) {
-            const bf16x8 t = *reinterpret_cast<const bf16x8*>(vn);
-            *reinterpret_cast<bf16x8*>(const_cast<bf16_t*>(vb) + (int64_t)j * ldv) = t;
-            return t;
-        }
+        if (own_new && j == Sk - 1) return vnew;
         return *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
     };
     const int32_t* mrow = key_mask ? key_mask + (int64_t)b * ld_mask : nullptr;
-    // key of (batch start j0, slot u): groups of KPI keys are dealt round-robin to the DEC_WPH waves of the head
-    auto key_of = [&](int j0, int u) { return j0 + (u * DEC_WPH + part) * KPI + sub; };
-    constexpr int STEP = KPI * DEC_WPH * DEC_U;
 
     for (int j0 = 0; j0 < Sk; j0 += STEP) {
         bf16x8 kv[DEC_U];
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
             const int j = key_of(j0, u);
-            kv[u] = (bf16x8){};
-            if (active && j < Sk) kv[u] = load_k(j);
+            if (j0 == 0) {
+                kv[u] = (own_new && j == Sk - 1) ? knew : kv0[u];
+            } else {
+                kv[u] = (bf16x8){};
+                if (active && j < Sk) kv[u] = load_k(j);
+            }
         }
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
@@ -499,13 +576,17 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
             if (head_ok && dl == 0 && j < Sk) sc[j] = (mrow && mrow[j] == 0) ? -FLT_MAX : d * scale;
         }
     }
-    // the first batch of V does not depend on the scores: fetch it under the exchange and the softmax
-    bf16x8 v0[DEC_U];
+    // without the image, the first batch of V is fetched under the exchange and the softmax
+    bf16x8 v0[VLDS ? 1 : DEC_U];
+    if (!VLDS) {
 #pragma unroll
-    for (int u = 0; u < DEC_U; ++u) {
-        const int j = key_of(0, u);
-        v0[u] = (bf16x8){};
-        if (active && j < Sk) v0[u] = load_v(j);
+        for (int u = 0; u < DEC_U; ++u) {
+            const int j = key_of(0, u);
+            v0[u] = (bf16x8){};
+            if (active && j < Sk) v0[u] = load_v(j);
+        }
+    } else {
+        __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);      // vmcnt(0): this wave's share of the V image has landed
     }
     __syncthreads();
     float mx = -FLT_MAX;
@@ -516,23 +597,26 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
     sum = wave_sum(sum);
 
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j0 = 0; j0 < Sk; j0 += STEP) {
-        bf16x8 vv[DEC_U];
-        float pj[DEC_U];
+    auto accumulate = [&](const bf16x8 (&vv)[DEC_U], int j0) {
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
             const int j = key_of(j0, u);
-            if (j0 == 0) vv[u] = v0[u];
-            else {
-                vv[u] = (bf16x8){};
-                if (active && j < Sk) vv[u] = load_v(j);
-            }
-            pj[u] = (active && j < Sk) ? __expf(sc[j] - mx) : 0.f;
+            const float pj = (active && j < Sk) ? __expf(sc[j] - mx) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += pj * (float)vv[u][e];
         }
+    };
+    if (!VLDS) accumulate(reinterpret_cast<const bf16x8 (&)[DEC_U]>(v0), 0);
+    for (int j0 = VLDS ? 0 : STEP; j0 < Sk; j0 += STEP) {
+        bf16x8 vv[DEC_U];
 #pragma unroll
-        for (int u = 0; u < DEC_U; ++u)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += pj[u] * (float)vv[u][e];
+        for (int u = 0; u < DEC_U; ++u) {
+            const int j = key_of(j0, u);
+            vv[u] = (bf16x8){};
+            if (active && j < Sk)
+                vv[u] = VLDS ? *reinterpret_cast<const bf16x8*>(vimg + (j * cpk + hh * (hd >> 3) + dl) * 16) : load_v(j);
+        }
+        accumulate(vv, j0);
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -573,9 +657,10 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
                               int64_t q_batch_rows, int64_t kv_batch_rows,
                               const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal,
                               float scale, float* lse, void* stream, int path,
-                              const void* k_new, const void* v_new, int64_t ld_new) {
+                              const void* k_new, const void* v_new, int64_t ld_new,
+                              const float* qkv_part = nullptr, int ks = 0, const float* qkv_bias = nullptr) {
     const bool g_force_valu = (path & 1) != 0;      // include/eavqa_test.h: bf16 on the vector-ALU kernels
-    if (!q || !k || !v || !o) return EAVQA_E_ARG;
+    if ((!q && !qkv_part) || !k || !v || !o) return EAVQA_E_ARG;
     int rc = check_common(dtype, B, H, Sq, Sk, hd);
     if (rc) return rc;
     if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return EAVQA_E_ALIGN;
@@ -591,26 +676,39 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
     p.bsk = kv_batch_rows > 0 ? kv_batch_rows : Sk;
     if (p.bsq < Sq || p.bsk < Sk) return EAVQA_E_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (decode_supported(dtype, Sq, Sk, hd, cu_seqlens, ldq, ldk, ldv, ldo) && !g_force_valu && eavqa_aligned16(q) && eavqa_aligned16(k) &&
+    if (decode_supported(dtype, Sq, Sk, hd, cu_seqlens, ldq, ldk, ldv, ldo) && !g_force_valu && (qkv_part || eavqa_aligned16(q)) && eavqa_aligned16(k) &&
         eavqa_aligned16(v) && eavqa_aligned16(o)) {
         const dim3 grid(B, (H + 3) / 4);
         const int blocks = B * ((H + 3) / 4);
         const int wph = blocks <= 256 ? 4 : (blocks <= 512 ? 2 : 1);
-        const size_t lds = ((size_t)4 * Sk + 4 * wph * 128) * sizeof(float);
+        const size_t v_image = (size_t)Sk * 4 * hd * 2;
+        const bool vlds = wph == 4 && v_image <= 128 * 1024;
+        const size_t lds = ((size_t)4 * Sk + 4 * wph * 128) * sizeof(float) + (vlds ? v_image : 0);
+        if (vlds) {
+            static bool configured[2] = {false, false};
+            const int slot = hd <= 64 ? 0 : 1;
+            if (!configured[slot]) {
+                const void* fn = hd <= 64 ? reinterpret_cast<const void*>(attn_decode_kernel<8, 4, 10, true>)
+                                          : reinterpret_cast<const void*>(attn_decode_kernel<16, 4, 10, true>);
+                if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return EAVQA_E_LAUNCH;
+                configured[slot] = true;
+            }
+        }
 #define EAVQA_DEC(LPK)                                                                                                       \
-    if (wph == 4) EAVQA_DEC2(LPK, 4); else if (wph == 2) EAVQA_DEC2(LPK, 2); else EAVQA_DEC2(LPK, 1)
-#define EAVQA_DEC2(LPK, WPH)                                                                                                 \
-    hipLaunchKernelGGL((attn_decode_kernel<LPK, WPH>), grid, dim3(256 * WPH), lds, s, reinterpret_cast<const bf16_t*>(q), ldq,  \
+    if (vlds) EAVQA_DEC2(LPK, 4, true); else if (wph == 4) EAVQA_DEC2(LPK, 4, false); else if (wph == 2) EAVQA_DEC2(LPK, 2, false); \
+    else EAVQA_DEC2(LPK, 1, false)
+#define EAVQA_DEC2(LPK, WPH, VL)                                                                                             \
+    hipLaunchKernelGGL((attn_decode_kernel<LPK, WPH, 10, VL>), grid, dim3(256 * WPH), lds, s, reinterpret_cast<const bf16_t*>(q), ldq,  \
                        reinterpret_cast<const bf16_t*>(k), ldk, reinterpret_cast<const bf16_t*>(v), ldv,                      \
                        reinterpret_cast<bf16_t*>(o), ldo, p.bsq, p.bsk, key_mask, p.ld_mask, lse, H, Sk, hd, scale,                  \
-                       reinterpret_cast<const bf16_t*>(k_new), reinterpret_cast<const bf16_t*>(v_new), ld_new)
+                       reinterpret_cast<const bf16_t*>(k_new), reinterpret_cast<const bf16_t*>(v_new), ld_new, qkv_part, ks, qkv_bias)
         if (hd <= 64) { EAVQA_DEC(8); } else { EAVQA_DEC(16); }
 #undef EAVQA_DEC
 #undef EAVQA_DEC2
         EAVQA_LAUNCH_CHECK();
         return EAVQA_OK;
     }
-    if (k_new || v_new) return EAVQA_E_SHAPE;          // the append form exists for the decode kernel only
+    if (k_new || v_new || qkv_part) return EAVQA_E_SHAPE;          // the append forms exist for the decode kernel only
     const bool wide = eavqa_attn_mfma::supported_wide(hd, Sq, Sk) && !(ldq % 8 || ldk % 8 || ldv % 8);
     if (dtype == EAVQA_BF16 && (eavqa_attn_mfma::supported(hd) || wide) && !g_force_valu) {
         eavqa_attn_mfma::Params m = {};
@@ -642,6 +740,15 @@ extern "C" int eavqa_attention_decode(int dtype, int B, int H, int Sk, int hd, c
     if (ld_new % 8 || !eavqa_aligned16(k_new) || !eavqa_aligned16(v_new)) return EAVQA_E_ALIGN;
     return attention_fwd_impl(dtype, B, H, 1, Sk, hd, q, ldq, k_cache, ldk, v_cache, ldv, o, ldo, 1, kv_batch_rows, key_mask, ld_mask,
                               nullptr, 1, scale, nullptr, stream, 0, k_new, v_new, ld_new);
+}
+
+extern "C" int eavqa_attention_decode_splitk(int dtype, int B, int H, int Sk, int hd, const float* qkv_partials, int ks, const float* qkv_bias,
+                                             void* k_cache, int64_t ldk, void* v_cache, int64_t ldv, int64_t kv_batch_rows, void* o, int64_t ldo,
+                                             const int32_t* key_mask, int64_t ld_mask, float scale, void* stream) {
+    if (!qkv_partials || ks <= 0) return EAVQA_E_ARG;
+    if ((H * hd) % 4 || !eavqa_aligned16(qkv_partials) || (qkv_bias && !eavqa_aligned16(qkv_bias))) return EAVQA_E_ALIGN;
+    return attention_fwd_impl(dtype, B, H, 1, Sk, hd, nullptr, 8, k_cache, ldk, v_cache, ldv, o, ldo, 1, kv_batch_rows, key_mask, ld_mask,
+                              nullptr, 1, scale, nullptr, stream, 0, nullptr, nullptr, 0, qkv_partials, ks, qkv_bias);
 }
 
 extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,

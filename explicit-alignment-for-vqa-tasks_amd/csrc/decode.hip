@@ -8,34 +8,50 @@
 //
 // Why split K over workgroups: with M <= 64 every workgroup needs the whole activation slab A, and the first skinny
 // kernel (16 columns x all of K per workgroup) pulled 2 bytes of A through the CU's L1 for every byte of weights: the
-// L2 -> CU path (about 55 GB/s per CU), not HBM, set its 2.4 TB/s.  Here a workgroup owns 64 columns x one K slice: its
-// A slice is staged ONCE in LDS (LDS-DMA, swizzled 64-byte rows as in the tiled GEMMs) and shared by the four waves, each
-// of which streams its own 16 weight rows straight into VGPRs (8 loads in flight per wave).  A-bytes per weight byte:
-// 16 MF / 64 = 0.5 (MF = 2), and N / 64 x ks workgroups keep every CU loading.  The partial sums (ks x M x N fp32, 10-20 %
-// of the weight bytes) are summed in a fixed order by the consumer, so the result does not depend on scheduling.
+// L2 -> CU path (about 55 GB/s per CU), not HBM, set its 2.4 TB/s.  Here a workgroup owns 128 columns x one K slice: its
+// A slice is staged ONCE in LDS (LDS-DMA, swizzled 64-byte rows as in the tiled GEMMs) and shared by the eight waves, each
+// of which streams its own 16 weight rows straight into VGPRs through a rolling window of 8 / 16 loads in flight.  A-bytes
+// per weight byte: 16 MF / 128 = 0.25 (MF = 2).  The partial sums (ks x M x N fp32, 5-20 % of the weight bytes) are summed
+// in a fixed order by the consumer, so the result does not depend on scheduling.  A pure-load kernel with the same access
+// pattern reads these matrices at 4.3-4.7 TB/s (tools/hbm_probe.hip; 5.7 TB/s for 250+ MB): that is the floor this kernel is
+// measured against, not 8 TB/s.
 #include "common.h"
 
 namespace {
 
 __device__ __forceinline__ int fswz(int row, int kc) { return row * 64 + ((kc ^ ((-(row >> 2)) & 3)) << 4); }
 
-constexpr int SK_COLS = 64;       // columns per workgroup (4 waves x 16)
-constexpr int SK_UNROLL = 8;      // weight loads in flight per wave (16 KiB): fewer dependent HBM round trips per slice
 
-template <int MF>
-__global__ __launch_bounds__(256) void gemm_bf16_splitk_kernel(const bf16_t* __restrict__ A, int64_t lda,
-                                                               const bf16_t* __restrict__ B, int64_t ldb,
-                                                               float* __restrict__ P, int M, int N, int KS) {
+// MF: 16-row fragments of A (M <= 16 MF); NF: 16-column fragments per wave; NW: waves per workgroup (columns per workgroup =
+// 16 NF NW: the A slice is staged once per workgroup, so A bytes per weight byte = 16 MF / (16 NF NW)); U: k-steps of weight loads in
+// flight per wave.
+template <int MF, int NF, int NW, int U>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16_splitk_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                   const bf16_t* __restrict__ B, int64_t ldb,
+                                                                   float* __restrict__ P, int M, int N, int KS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TILE = 16 * MF * 64;                      // bytes of one [16 MF rows][32 k] A tile
+    constexpr int COLS = 16 * NF * NW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.x * SK_COLS, slice = blockIdx.y, k0 = slice * KS;
+    const int n0 = blockIdx.x * COLS + wave * 16 * NF, slice = blockIdx.y, k0 = slice * KS;
     const int nsteps = KS >> 5;
+
+    // ---- this wave's 16 NF weight rows: the first U k-steps go out before anything else (they are the HBM round trip that
+    //      bounds the workgroup's life; the A slice below comes from L2)
+    const int x = lane & 15, g = lane >> 4;
+    const bf16_t* bp[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) bp[j] = B + (int64_t)min(n0 + 16 * j + x, N - 1) * ldb + k0 + 8 * g;
+    bf16x8 bf[U][NF];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) bf[u][j] = *reinterpret_cast<const bf16x8*>(bp[j] + 32 * min(u, nsteps - 1));
 
     // ---- stage the A slice: chunk c -> tile c / (64 MF), row (c % (64 MF)) >> 2, physical slot c & 3
     const int total = nsteps * 64 * MF;
-    for (int base = wave * 64; base < total; base += 256) {
+    for (int base = wave * 64; base < total; base += 64 * NW) {
         const int c = base + lane;
         if (c < total) {
             const int t = c / (64 * MF), within = c % (64 * MF);
@@ -45,54 +61,52 @@ __global__ __launch_bounds__(256) void gemm_bf16_splitk_kernel(const bf16_t* __r
                                              (__attribute__((address_space(3))) void*)(smem + base * 16), 16, 0, 0);
         }
     }
-
-    // ---- this wave's 16 weight rows
-    const int x = lane & 15, g = lane >> 4;
-    const bf16_t* bp = B + (int64_t)min(n0 + wave * 16 + x, N - 1) * ldb + k0 + 8 * g;
-    f32x4 acc[MF];
+    f32x4 acc[MF][NF];
 #pragma unroll
-    for (int i = 0; i < MF; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int a_off = fswz(x, g);
-
-    bf16x8 bf[SK_UNROLL];
-#pragma unroll
-    for (int u = 0; u < SK_UNROLL; ++u)
-        bf[u] = *reinterpret_cast<const bf16x8*>(bp + 32 * min(u, nsteps - 1));
     __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);     // vmcnt(0): A slice (and the first weights) have landed
     __syncthreads();
 
-    for (int s0 = 0; s0 < nsteps; s0 += SK_UNROLL) {
-        bf16x8 cur[SK_UNROLL];
+    // rolling window: the registers of k-step s are refilled with k-step s + U as soon as its MFMAs are issued, so U loads
+    // per fragment column stay in flight for the whole slice
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
 #pragma unroll
-        for (int u = 0; u < SK_UNROLL; ++u) cur[u] = bf[u];
-        if (s0 + SK_UNROLL < nsteps) {
+        for (int u = 0; u < U; ++u) {
+            bf16x8 w[NF];
 #pragma unroll
-            for (int u = 0; u < SK_UNROLL; ++u)
-                bf[u] = *reinterpret_cast<const bf16x8*>(bp + 32 * min(s0 + SK_UNROLL + u, nsteps - 1));
-        }
+            for (int j = 0; j < NF; ++j) w[j] = bf[u][j];
+            if (s0 + U + u < nsteps) {
 #pragma unroll
-        for (int u = 0; u < SK_UNROLL; ++u) {
+                for (int j = 0; j < NF; ++j) bf[u][j] = *reinterpret_cast<const bf16x8*>(bp[j] + 32 * (s0 + U + u));
+            }
             if (s0 + u < nsteps) {
                 const char* tile = smem + (s0 + u) * TILE;
 #pragma unroll
                 for (int i = 0; i < MF; ++i) {
                     const bf16x8 af = *reinterpret_cast<const bf16x8*>(tile + a_off + i * 1024);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, cur[u], acc[i], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, w[j], acc[i][j], 0, 0, 0);
                 }
             }
         }
     }
 
-    const int n = n0 + wave * 16 + x;
-    if (n < N) {
-        float* out = P + (int64_t)slice * M * N + n;
 #pragma unroll
-        for (int i = 0; i < MF; ++i)
+    for (int j = 0; j < NF; ++j) {
+        const int n = n0 + 16 * j + x;
+        if (n < N) {
+            float* out = P + (int64_t)slice * M * N + n;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = 16 * i + 4 * g + r;
-                if (m < M) out[(int64_t)m * N] = acc[i][r];
-            }
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * i + 4 * g + r;
+                    if (m < M) out[(int64_t)m * N] = acc[i][j][r];
+                }
+        }
     }
 }
 
@@ -124,28 +138,29 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(int M, int N, const 
     else elem<T>::st4(reinterpret_cast<T*>(d.dst) + (int64_t)m * d.ld + nl, v);
 }
 
-// one 256-thread workgroup per row (a decode step has at most 64 rows: parallelism must come from inside the row), the
-// partial-sum loads of four slices in flight at once: x = x_in + bias + sum_s P[s]; y = LN(x) * gamma + beta
-__device__ __forceinline__ float block_sum4(float v, float* red) {
+// one 512-thread workgroup per row (a decode step has at most 64 rows: parallelism must come from inside the row), the
+// partial-sum loads of eight slices in flight at once: x = x_in + bias + sum_s P[s]; y = LN(x) * gamma + beta
+constexpr int LNS_NT = 512;
+__device__ __forceinline__ float block_sum8(float v, float* red) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 }
 
 template <typename T, int NV>
-__global__ __launch_bounds__(256) void ln_splitk_kernel(int rows, int cols, const float* __restrict__ x_in, int64_t ldx,
-                                                        const float* __restrict__ P, int ks, const float* __restrict__ bias,
-                                                        float* __restrict__ x_out, int64_t ldxo, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, float eps, T* __restrict__ y, int64_t ldy) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(LNS_NT) void ln_splitk_kernel(int rows, int cols, const float* __restrict__ x_in, int64_t ldx,
+                                                           const float* __restrict__ P, int ks, const float* __restrict__ bias,
+                                                           float* __restrict__ x_out, int64_t ldxo, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, T* __restrict__ y, int64_t ldy) {
+    __shared__ float red[LNS_NT / 64];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = cols >> 2;
     float4 v[NV], gm[NV], bt[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + LNS_NT * i;
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < nv) {
             v[i] = *reinterpret_cast<const float4*>(x_in + (int64_t)row * ldx + 4 * c);
@@ -157,53 +172,58 @@ __global__ __launch_bounds__(256) void ln_splitk_kernel(int rows, int cols, cons
     const int64_t slice = (int64_t)rows * cols;
     const float* prow = P + (int64_t)row * cols;
     int sl = 0;
-    for (; sl + 4 <= ks; sl += 4) {
-        float4 t[4][NV];
+    for (; sl + 8 <= ks; sl += 8) {
+        float4 t[8][NV];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int c = tid + 256 * i;
+                const int c = tid + LNS_NT * i;
                 t[u][i] = c < nv ? *reinterpret_cast<const float4*>(prow + (sl + u) * slice + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)          // slices are added in index order: the sum does not depend on scheduling
+        for (int u = 0; u < 8; ++u)          // slices are added in index order: the sum does not depend on scheduling
 #pragma unroll
             for (int i = 0; i < NV; ++i) { v[i].x += t[u][i].x; v[i].y += t[u][i].y; v[i].z += t[u][i].z; v[i].w += t[u][i].w; }
     }
-    for (; sl < ks; ++sl) {
+    if (sl < ks) {
+        float4 t[8][NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = tid + 256 * i;
-            if (c < nv) {
-                const float4 t = *reinterpret_cast<const float4*>(prow + sl * slice + 4 * c);
-                v[i].x += t.x; v[i].y += t.y; v[i].z += t.z; v[i].w += t.w;
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = tid + LNS_NT * i;
+                t[u][i] = (c < nv && sl + u < ks) ? *reinterpret_cast<const float4*>(prow + (sl + u) * slice + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (sl + u < ks) { v[i].x += t[u][i].x; v[i].y += t[u][i].y; v[i].z += t[u][i].z; v[i].w += t[u][i].w; }
     }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + LNS_NT * i;
         if (c < nv) {
             if (x_out) *reinterpret_cast<float4*>(x_out + (int64_t)row * ldxo + 4 * c) = v[i];
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }
-    const float mu = block_sum4(s, red) / (float)cols;
+    const float mu = block_sum8(s, red) / (float)cols;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + LNS_NT * i;
         if (c < nv) {
             const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
             q += (a * a + b * b) + (cc * cc + d * d);
         }
     }
-    const float rs = rsqrtf(block_sum4(q, red) / (float)cols + eps);
+    const float rs = rsqrtf(block_sum8(q, red) / (float)cols + eps);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int c = tid + 256 * i;
+        const int c = tid + LNS_NT * i;
         if (c < nv) {
             float4 o;
             o.x = (v[i].x - mu) * rs * gm[i].x + bt[i].x;
@@ -219,22 +239,27 @@ inline int splitk_mf(int M) { return M <= 16 ? 1 : (M <= 32 ? 2 : 4); }
 
 }  // namespace
 
+// Plan (measured on OPT-2.7B's four decode shapes at M = 32, tools/decode_bench.py --sweep, profiles/round2_decode.md): 8-wave
+// workgroups of 128 columns (the A slice is staged once per 128 columns: a quarter of a byte of A per weight byte), ONE workgroup per
+// CU where the shape allows it - the largest ks with (N / 128) x ks <= 256 and slices of at least 256 k-values - and a 16-deep
+// weight-load window when the slice has 16+ steps.  Slices stay <= 1024 k-values (64 KiB of LDS at M <= 32).
 extern "C" int eavqa_gemm_splitk_plan(int M, int N, int K) {
     if (M <= 0 || M > 64 || N <= 0 || K <= 0 || K % 32) return 0;
-    const int mf = splitk_mf(M), groups = (N + SK_COLS - 1) / SK_COLS;
+    const int mf = splitk_mf(M), groups = (N + 127) / 128;
     int best = 0;
-    for (int ks = 1; ks <= 16; ++ks) {
+    for (int ks = 1; ks <= 32; ++ks) {
         if (K % (32 * ks)) continue;
-        const int lds = (K / ks) * mf * 32;              // bytes of the staged A slice
-        if (lds > 64 * 1024) continue;                   // two workgroups per CU
-        best = ks;
-        if (groups * ks >= 320) break;                   // enough workgroups to keep every CU streaming
+        const int KS = K / ks;
+        if (KS * mf * 32 > 64 * 1024) continue;          // staged A slice
+        if (!best) best = ks;                            // smallest admissible split
+        if (groups * ks <= 256 && KS >= 256) best = ks;
     }
     return best;
 }
 
-extern "C" int eavqa_gemm_splitk(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
-                                 float* partials, int ks, void* stream) {
+namespace {
+int gemm_splitk_impl(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb, float* partials, int ks,
+                     void* stream, int unroll) {
     if (dtype != EAVQA_BF16) return EAVQA_E_DTYPE;
     if (!A || !B || !partials || M <= 0 || M > 64 || N <= 0 || K <= 0 || ks <= 0) return EAVQA_E_ARG;
     if (K % (32 * ks) || lda < K || ldb < K) return EAVQA_E_SHAPE;
@@ -242,19 +267,41 @@ extern "C" int eavqa_gemm_splitk(int dtype, int M, int N, int K, const void* A, 
     const int mf = splitk_mf(M), KS = K / ks;
     const int lds = KS * mf * 32;
     if (lds > 150 * 1024) return EAVQA_E_SHAPE;
+    // selector: bits [7:0] U (8 / 16), [11:8] NW (4 / 8), [15:12] NF (1 / 2); 0 fields = defaults
+    const int U = (unroll & 0xFF) ? (unroll & 0xFF) : (KS >= 512 ? 16 : 8);
+    const int NW = ((unroll >> 8) & 0xF) ? ((unroll >> 8) & 0xF) : 8, NF = ((unroll >> 12) & 0xF) ? ((unroll >> 12) & 0xF) : 1;
+    if ((U != 8 && U != 16) || (NW != 4 && NW != 8) || (NF != 1 && NF != 2)) return EAVQA_E_ARG;
     typedef void (*kernel_t)(const bf16_t*, int64_t, const bf16_t*, int64_t, float*, int, int, int);
-    const kernel_t kernel = mf == 1 ? gemm_bf16_splitk_kernel<1> : (mf == 2 ? gemm_bf16_splitk_kernel<2> : gemm_bf16_splitk_kernel<4>);
-    static bool configured[3] = {false, false, false};
-    const int slot = mf == 1 ? 0 : (mf == 2 ? 1 : 2);
-    if (!configured[slot]) {
+#define EAVQA_SK_ROW(MFV) {{{gemm_bf16_splitk_kernel<MFV, 1, 4, 8>, gemm_bf16_splitk_kernel<MFV, 1, 4, 16>},   \
+                            {gemm_bf16_splitk_kernel<MFV, 1, 8, 8>, gemm_bf16_splitk_kernel<MFV, 1, 8, 16>}},  \
+                           {{gemm_bf16_splitk_kernel<MFV, 2, 4, 8>, gemm_bf16_splitk_kernel<MFV, 2, 4, 16>},   \
+                            {gemm_bf16_splitk_kernel<MFV, 2, 8, 8>, gemm_bf16_splitk_kernel<MFV, 2, 8, 16>}}}
+    static const kernel_t kernels[3][2][2][2] = {EAVQA_SK_ROW(1), EAVQA_SK_ROW(2), EAVQA_SK_ROW(4)};      // [mf][NF][NW][U]
+#undef EAVQA_SK_ROW
+    static bool configured[3][2][2][2] = {};
+    const int im = mf == 1 ? 0 : (mf == 2 ? 1 : 2), in = NF - 1, iw = NW == 8, iu = U == 16;
+    const kernel_t kernel = kernels[im][in][iw][iu];
+    if (!configured[im][in][iw][iu]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
             return EAVQA_E_LAUNCH;
-        configured[slot] = true;
+        configured[im][in][iw][iu] = true;
     }
-    hipLaunchKernelGGL(kernel, dim3((N + SK_COLS - 1) / SK_COLS, ks), dim3(256), lds, reinterpret_cast<hipStream_t>(stream),
+    const int cols = 16 * NF * NW;
+    hipLaunchKernelGGL(kernel, dim3((N + cols - 1) / cols, ks), dim3(64 * NW), lds, reinterpret_cast<hipStream_t>(stream),
                        reinterpret_cast<const bf16_t*>(A), lda, reinterpret_cast<const bf16_t*>(B), ldb, partials, M, N, KS);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
+}
+}  // namespace
+
+extern "C" int eavqa_gemm_splitk(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                 float* partials, int ks, void* stream) {
+    return gemm_splitk_impl(dtype, M, N, K, A, lda, B, ldb, partials, ks, stream, 0);
+}
+
+extern "C" int eavqa_gemm_splitk_ex(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                                    float* partials, int ks, void* stream, int unroll) {
+    return gemm_splitk_impl(dtype, M, N, K, A, lda, B, ldb, partials, ks, stream, unroll);
 }
 
 extern "C" int eavqa_splitk_finish(int dtype, int M, int N, const float* partials, int ks, const float* bias, int act,
@@ -286,8 +333,8 @@ extern "C" int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float
     if (!x_in || !gamma || !beta || !y || rows <= 0 || cols <= 0 || ks < 0 || (ks > 0 && !partials)) return EAVQA_E_ARG;
     if (cols % 4 || cols > 64 * 4 * 16) return EAVQA_E_SHAPE;
     if (ldx % 4 || ldy % 4 || (x_out && ld_out % 4)) return EAVQA_E_ALIGN;
-    const int nv = (cols / 4 + 255) / 256;
-    const dim3 grid(rows), block(256);
+    const int nv = (cols / 4 + LNS_NT - 1) / LNS_NT;
+    const dim3 grid(rows), block(LNS_NT);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define EAVQA_LNS(T, NV)                                                                                                    \
     hipLaunchKernelGGL((ln_splitk_kernel<T, NV>), grid, block, 0, s, rows, cols, x_in, ldx, partials, ks, bias, x_out, ld_out, \

@@ -68,6 +68,7 @@ extern "C" int eavqa_lm_block_forward(int dtype, int n_layer, const eavqa_lm_lay
         // (the compile-time constant below), not taken.
         constexpr bool kFusedDecode = false;
         const bool fused = kFusedDecode && (E % 64) == 0 && (hd % 8) == 0 && hd <= 128 && Sk <= 3584;
+        const bool attn_from_partials = (hd % 8) == 0 && hd <= 128 && Sk <= 3584 && (E % 8) == 0;
         float* part = reinterpret_cast<float*>(w);
         float* part2 = reinterpret_cast<float*>(w + (d.part_bytes - align_up((size_t)d.ks_fc2 * rows * E * 4)));
         for (int l = 0; l < n_layer; ++l) {
@@ -84,6 +85,11 @@ extern "C" int eavqa_lm_block_forward(int dtype, int n_layer, const eavqa_lm_lay
                                      nullptr, 0, stream))) return rc;
                 if ((rc = eavqa_attention_decode(dtype, B, H, Sk, hd, qkv, 3 * E, L.k_cache, E, L.v_cache, E, S_max, qkv + (size_t)E * es,
                                                  qkv + (size_t)2 * E * es, 3 * E, ctx, E, key_mask, ld_mask, scale, stream))) return rc;
+            } else if (attn_from_partials) {
+                // the decode attention sums the QKV partial sums itself (q, and the new K / V rows, which it appends to the cache)
+                if ((rc = eavqa_gemm_splitk(dtype, rows, 3 * E, E, a, E, L.w_qkv, E, part, d.ks_qkv, stream))) return rc;
+                if ((rc = eavqa_attention_decode_splitk(dtype, B, H, Sk, hd, part, d.ks_qkv, L.b_qkv, L.k_cache, E, L.v_cache, E, S_max, ctx, E,
+                                                        key_mask, ld_mask, scale, stream))) return rc;
             } else {
                 if ((rc = eavqa_gemm_splitk(dtype, rows, 3 * E, E, a, E, L.w_qkv, E, part, d.ks_qkv, stream))) return rc;
                 // q -> qkv[:, :E]; k, v -> cache rows (sample m at row m * S_max + row0)

@@ -172,6 +172,17 @@ def attention_decode(q: Tensor, k_cache: Tensor, v_cache: Tensor, k_new: Tensor,
     return o
 
 
+def attention_decode_splitk(part: Tensor, bias: Optional[Tensor], k_cache: Tensor, v_cache: Tensor, B: int, H: int, Sk: int, hd: int, *,
+                            kv_batch_rows: int, key_mask: Optional[Tensor] = None, ld_mask: int = 0, scale: float = 1.0,
+                            out: Optional[Tensor] = None) -> Tensor:
+    """``attention_decode`` straight from the QKV projection's split-K partial sums ``part`` [ks, B, 3*H*hd] (+ ``bias`` [3*H*hd])."""
+    _dev(part)
+    o = out if out is not None else torch.empty((B, H * hd), device=part.device, dtype=k_cache.dtype)
+    call("eavqa_attention_decode_splitk", dtype_id(k_cache.dtype), B, H, Sk, hd, _p(part), part.shape[0], _p(bias), _p(k_cache), _ld(k_cache),
+         _p(v_cache), _ld(v_cache), kv_batch_rows, _p(o), _ld(o), _p(key_mask), ld_mask, float(scale), _stream())
+    return o
+
+
 def attention_bwd(q, k, v, o, d_o, lse, B, H, Sq, Sk, hd, *, key_mask=None, causal=False, scale=1.0,
                   dq=None, dk=None, dv=None, cu_seqlens=None):
     _dev(q)
@@ -357,16 +368,20 @@ def transpose(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
     return y
 
 
-def gemm_splitk(a: Tensor, b: Tensor, ks: Optional[int] = None) -> Tensor:
-    """fp32 partial sums [ks, M, N] of a [M,K] @ b [N,K]^T (bf16, M <= 64): the decode-step weight-streaming GEMM."""
+def gemm_splitk(a: Tensor, b: Tensor, ks: Optional[int] = None, unroll: int = 0, out: Optional[Tensor] = None) -> Tensor:
+    """fp32 partial sums [ks, M, N] of a [M,K] @ b [N,K]^T (bf16, M <= 64): the decode-step weight-streaming GEMM.
+    ``unroll`` (tests / tools only) selects the depth of the weight-load window through ``eavqa_gemm_splitk_ex``."""
     M, K = a.shape
     N = b.shape[0]
     if ks is None:
         ks = int(_lib.load().eavqa_gemm_splitk_plan(M, N, K))
         if ks <= 0:
             raise _lib.EavqaError(f"eavqa_gemm_splitk: unsupported shape M={M} N={N} K={K}")
-    part = torch.empty((ks, M, N), device=a.device, dtype=torch.float32)
-    call("eavqa_gemm_splitk", dtype_id(a.dtype), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(part), ks, _stream())
+    part = out if out is not None else torch.empty((ks, M, N), device=a.device, dtype=torch.float32)
+    if unroll:
+        call("eavqa_gemm_splitk_ex", dtype_id(a.dtype), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(part), ks, _stream(), unroll)
+    else:
+        call("eavqa_gemm_splitk", dtype_id(a.dtype), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(part), ks, _stream())
     return part
 
 

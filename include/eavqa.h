@@ -127,6 +127,13 @@ int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,
 int eavqa_attention_decode(int dtype, int B, int H, int Sk, int hd, const void* q, int64_t ldq, void* k_cache, int64_t ldk,
                            void* v_cache, int64_t ldv, int64_t kv_batch_rows, const void* k_new, const void* v_new, int64_t ld_new,
                            void* o, int64_t ldo, const int32_t* key_mask, int64_t ld_mask, float scale, void* stream);
+/* The same step straight from the split-K partial sums of the QKV projection (eavqa_gemm_splitk: qkv_partials [ks][B][3 H hd] fp32,
+ * columns q | k | v): every lane sums the slices in index order, adds qkv_bias (may be NULL) and rounds to bfloat16 - bit for bit the
+ * q / K / V that eavqa_splitk_finish would have stored - appends K / V at position Sk-1 and attends.  One kernel instead of three
+ * (finish, append, attention) per layer of a decode step. */
+int eavqa_attention_decode_splitk(int dtype, int B, int H, int Sk, int hd, const float* qkv_partials, int ks, const float* qkv_bias,
+                                  void* k_cache, int64_t ldk, void* v_cache, int64_t ldv, int64_t kv_batch_rows, void* o, int64_t ldo,
+                                  const int32_t* key_mask, int64_t ld_mask, float scale, void* stream);
 /* Backward (dense batches only: batch_rows = Sq / Sk): dq/dk/dv in `dtype`, addressed as q/k/v
  * with leading dims lddq/lddk/lddv.
  * delta: float32 scratch [B,H,Sq] (rowsum(do*o), written by the call). */

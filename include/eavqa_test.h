@@ -46,6 +46,11 @@ int eavqa_attention_bwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
                            const int32_t* key_mask, const int32_t* cu_seqlens, int causal, float scale,
                            const float* lse, float* delta, void* stream, int path);
 
+/* eavqa_gemm_splitk with the depth of the per-wave weight-load window as an argument: 8 or 16 k-steps (KiB) in flight per wave;
+ * 0 = the library default. */
+int eavqa_gemm_splitk_ex(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
+                         float* partials, int ks, void* stream, int unroll);
+
 #ifdef __cplusplus
 }
 #endif

@@ -371,6 +371,34 @@ def test_attention_kv_cache_batch_stride(ops):
     assert (o.cpu().view(B, 1, H, hd) - ref.float()).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,hd,Sk,S_max,ks", [(32, 32, 80, 151, 160, 4), (5, 12, 64, 1, 8, 1), (33, 20, 64, 97, 120, 3), (64, 32, 128, 200, 256, 2),
+                                                 (3, 6, 96, 161, 170, 5)])
+def test_attention_decode_from_qkv_partial_sums(ops, B, H, hd, Sk, S_max, ks):
+    """eavqa_attention_decode_splitk == eavqa_splitk_finish (q | K row | V row) followed by eavqa_attention_decode, bit for bit: output,
+    and both caches."""
+    E = H * hd
+    g = torch.Generator().manual_seed(B + Sk)
+    kc = torch.randn(B, S_max, E, generator=g).to(torch.bfloat16)
+    vc = torch.randn(B, S_max, E, generator=g).to(torch.bfloat16)
+    part = torch.randn(ks, B, 3 * E, generator=g).to(DEV)
+    bias = torch.randn(3 * E, generator=g).to(DEV)
+    mask = (torch.rand(B, S_max, generator=g) > 0.2).int()
+    mask[:, Sk - 1] = 1
+    scale = hd ** -0.5
+    # the three-kernel route
+    qkv = torch.empty(B, 3 * E, dtype=torch.bfloat16, device=DEV)
+    ops.splitk_finish(part, [qkv], bias=bias)
+    k1, v1 = kc.to(DEV), vc.to(DEV)
+    want = ops.attention_decode(qkv[:, :E], k1.view(B * S_max, E), v1.view(B * S_max, E), qkv[:, E:2 * E], qkv[:, 2 * E:], B, H, Sk, hd,
+                                kv_batch_rows=S_max, key_mask=mask.to(DEV), ld_mask=S_max, scale=scale)
+    k2, v2 = kc.to(DEV), vc.to(DEV)
+    got = ops.attention_decode_splitk(part, bias, k2.view(B * S_max, E), v2.view(B * S_max, E), B, H, Sk, hd, kv_batch_rows=S_max,
+                                      key_mask=mask.to(DEV), ld_mask=S_max, scale=scale)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    assert torch.equal(k2[:, Sk - 1], qkv[:, E:2 * E]) and torch.equal(v2[:, Sk - 1], qkv[:, 2 * E:])
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("B,H,Sk,hd,masked", [(3, 5, 157, 80, True), (2, 8, 300, 128, False), (2, 4, 40, 64, True), (1, 3, 7, 32, False),
                                               (32, 32, 160, 80, True), (1, 4, 3584, 64, False), (1, 4, 3600, 64, False)])
 def test_attention_decode_step(ops, B, H, Sk, hd, masked):
@@ -671,6 +699,17 @@ def test_gemm_splitk_and_finish(ops, M, N, K):
         x = torch.empty(M, N, device=DEV)
         ops.splitk_finish(part, [x], bias=bias.to(DEV), residual=res.to(DEV))
         assert (x.cpu() - (ref.float() + bias + res)).abs().max().item() <= 1e-3 * math.sqrt(K)
+
+
+@pytest.mark.parametrize("sel", [8, 16, 0x0808, 0x0810, 0x2408, 0x2410, 0x2808, 0x2810])
+@pytest.mark.parametrize("M,N,K", [(32, 7680, 2560), (9, 200, 96), (64, 2560, 1024)])
+def test_gemm_splitk_every_kernel_variant(ops, sel, M, N, K):
+    """eavqa_gemm_splitk_ex: load-window depth 8 / 16 x 4 / 8 waves per workgroup x 16 / 32 columns per wave (bits of `sel`)."""
+    a = rnd(M, K, dtype=torch.bfloat16, seed=1, scale=0.5)
+    b = rnd(N, K, dtype=torch.bfloat16, seed=2, scale=0.5)
+    ref = a.double() @ b.double().T
+    part = ops.gemm_splitk(a.to(DEV), b.to(DEV), unroll=sel)
+    assert (part.double().sum(0).cpu() - ref).abs().max().item() <= 1e-3 * math.sqrt(K)
 
 
 def test_gemm_splitk_is_deterministic(ops):

@@ -25,9 +25,32 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--hot", action="store_true", help="reuse one weight / cache buffer (served from L2 / Infinity Cache)")
+    ap.add_argument("--sweep", action="store_true", help="split-K: every admissible ks x load-window depth (8 / 16) per decode shape")
     a = ap.parse_args()
     dev, bf = "cuda", torch.bfloat16
     E, H, hd, F = 2560, 32, 80, 10240
+    if a.sweep:
+        for N, K, what in ((3 * E, E, "qkv"), (E, E, "proj"), (F, E, "fc1"), (E, F, "fc2")):
+            nb = max(2, int(6e8 / (2.0 * N * K)) + 1)
+            ws = [(torch.randn(N, K, device=dev) * 0.02).to(bf) for _ in range(nb)]
+            x = torch.randn(32, K, device=dev).to(bf)
+            mb = N * K * 2 / 1e6
+            plan = ops.gemm_splitk(x, ws[0]).shape[0]
+            for ks in (1, 2, 4, 5, 8, 10, 16, 20):
+                if K % (32 * ks) or (K // ks) * 2 * 32 > 150 * 1024:
+                    continue
+                part = torch.empty((ks, 32, N), device=dev, dtype=torch.float32)
+                row = []
+                for nf in (1, 2):
+                    for nw in (4, 8):
+                        for unroll in (8, 16):
+                            sel = unroll | (nw << 8) | (nf << 12)
+                            us = timed(lambda i: ops.gemm_splitk(x, ws[i % nb], ks=ks, unroll=sel, out=part), a.iters)
+                            row.append(f"{us:5.1f}")
+                print(f"{what:5s} ks={ks:2d}{'*' if ks == plan else ' '} KS={K // ks:5d}  [cols/wave 16: 4w U8 U16 | 8w U8 U16 || cols/wave 32: 4w U8 U16 | 8w U8 U16] us: "
+                      + " ".join(row) + f"   (stream floor {mb / 5.0:5.1f} us at 5 TB/s)", flush=True)
+            del ws
+        return
     print("-- attention decode (OPT-2.7B heads, 160 cached keys), KV rotated over 12 layers' worth")
     for B in (8, 16, 32, 64, 128):
         Smax, Sk = 169, 160
