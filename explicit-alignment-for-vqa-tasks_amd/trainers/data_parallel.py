@@ -55,13 +55,16 @@ class GradSync:
     gradients in the buffer are already summed over the ranks (the MLP mapper's factor exchange, models/clipcap.py), only
     ``grad_scale`` is still needed."""
 
-    def __init__(self, flat_grad: torch.Tensor, world: Optional[int] = None, group=None, exchange: bool = True):
+    def __init__(self, flat_grad: torch.Tensor, world: Optional[int] = None, group=None, exchange: bool = True,
+                 collectives_in_group_of_one: bool = False):
         self.buf = flat_grad
         self.group = group
-        self.exchange = exchange
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        # a group of one needs no exchange; `collectives_in_group_of_one` issues the collective anyway (the RCCL path on a one-GPU box:
+        # tests/test_rccl_gpu.py)
+        self.exchange = exchange and (self.world > 1 or collectives_in_group_of_one)
         self.on_gpu = flat_grad.is_cuda
-        self.stream = torch.cuda.Stream() if (self.on_gpu and self.world > 1 and exchange) else None
+        self.stream = torch.cuda.Stream() if (self.on_gpu and self.exchange) else None
         self._pending = None
 
     @property
@@ -71,7 +74,7 @@ class GradSync:
 
     def start(self) -> None:
         """Enqueue the all-reduce after everything already queued on the current stream."""
-        if self.world == 1 or not self.exchange:
+        if not self.exchange:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -82,7 +85,7 @@ class GradSync:
 
     def finish(self) -> None:
         """Make the current stream wait for the exchange (call right before the optimiser step)."""
-        if self.world == 1 or self._pending is None:
+        if self._pending is None:
             return
         self._pending.wait()
         if self.stream is not None:

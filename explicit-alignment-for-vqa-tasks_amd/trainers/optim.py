@@ -121,7 +121,7 @@ class ShardedAdamW:
     ``adamw`` is the update kernel (``ops.adamw``; the CPU tests inject a torch restatement - the product path has no CPU fallback)."""
 
     def __init__(self, flat, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, *, group=None,
-                 n_buckets: int = 4, adamw=None):
+                 n_buckets: int = 4, adamw=None, collectives_in_group_of_one: bool = False):
         import torch.distributed as dist
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -143,7 +143,9 @@ class ShardedAdamW:
         self.v = torch.zeros(n_buckets * self.piece, device=dev)
         self.gshard = torch.empty(n_buckets * self.piece, device=dev)
         self.step_count = 0
-        self.stream = torch.cuda.Stream() if (flat.master.is_cuda and self.world > 1) else None
+        # a group of one needs no collectives; `collectives_in_group_of_one` issues them anyway (the RCCL path on a one-GPU box)
+        self.multi = self.world > 1 or (collectives_in_group_of_one and dist.is_initialized())
+        self.stream = torch.cuda.Stream() if (flat.master.is_cuda and self.multi) else None
         self._busy = False
 
     @property
@@ -161,7 +163,7 @@ class ShardedAdamW:
         kw = dict(step=self.step_count, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
                   grad_scale=grad_scale)
         lowp = fl.shadow is not fl.master
-        multi = self.world > 1
+        multi = self.multi
         if self.small:
             if multi:
                 dist.all_reduce(fl.grad[:self.small], op=dist.ReduceOp.SUM, group=self.group)
@@ -209,7 +211,7 @@ class ShardedAdamW:
         """The whole fp32 master copy on every rank (checkpoints): non-owned shards are stale between steps in bf16 mode."""
         import torch.distributed as dist
         fl = self.flat
-        if self.world > 1 and fl.shadow is not fl.master:
+        if self.multi and fl.shadow is not fl.master:
             for b in range(self.n_buckets):
                 lo, hi, mine = self._bucket(b)
                 dist.all_gather_into_tensor(fl.master[lo:hi], fl.master[mine:mine + self.piece], group=self.group)
