@@ -240,7 +240,7 @@ template <int WM, int WN, int MF, int NF, int NST_, int LW_> struct K64SGeo {
     static_assert((TBM + TBN) % 8 == 0 && P_LO >= 1, "stage must cut into whole pieces, at least one per loader");
     static_assert(16 * MFC * PITCH * 4 <= RING && MF % MFC == 0 && (MFC == MF || SP == 1), "C staging pass must fit the ring");
     static_assert(WM % SP == 0 && RING <= 160 * 1024 && NT <= 1024, "geometry");
-    static_assert(P_HI * (NST - 1) <= 63 && NST >= 2 && NST <= 4, "vmcnt field");
+    static_assert(P_HI * (NST - 1) <= 63 && NST >= 2 && NST <= 6, "vmcnt field");
 };
 
 // The loader role (shared by the bf16 and the fp8 kernels): operands are addressed in BYTES - a stage row is 128 bytes of the
@@ -271,13 +271,17 @@ __device__ __forceinline__ void k64s_loader_role(const char* A, const char* B, i
     };
     auto wait_tiles = [&](int tiles) {                                      // at most `tiles` later tiles of this wave still in flight
         if (hi) {
-            if (NST >= 4 && tiles >= 3) wait_vm<3 * G::P_HI>();
-            else if (NST >= 3 && tiles >= 2) wait_vm<2 * G::P_HI>();
+            if (NST >= 6 && tiles >= 5) wait_vm<(NST >= 6 ? 5 : 0) * G::P_HI>();
+            else if (NST >= 5 && tiles >= 4) wait_vm<(NST >= 5 ? 4 : 0) * G::P_HI>();
+            else if (NST >= 4 && tiles >= 3) wait_vm<(NST >= 4 ? 3 : 0) * G::P_HI>();
+            else if (NST >= 3 && tiles >= 2) wait_vm<(NST >= 3 ? 2 : 0) * G::P_HI>();
             else if (tiles >= 1) wait_vm<G::P_HI>();
             else wait_vm<0>();
         } else {
-            if (NST >= 4 && tiles >= 3) wait_vm<3 * G::P_LO>();
-            else if (NST >= 3 && tiles >= 2) wait_vm<2 * G::P_LO>();
+            if (NST >= 6 && tiles >= 5) wait_vm<(NST >= 6 ? 5 : 0) * G::P_LO>();
+            else if (NST >= 5 && tiles >= 4) wait_vm<(NST >= 5 ? 4 : 0) * G::P_LO>();
+            else if (NST >= 4 && tiles >= 3) wait_vm<(NST >= 4 ? 3 : 0) * G::P_LO>();
+            else if (NST >= 3 && tiles >= 2) wait_vm<(NST >= 3 ? 2 : 0) * G::P_LO>();
             else if (tiles >= 1) wait_vm<G::P_LO>();
             else wait_vm<0>();
         }
