@@ -919,11 +919,13 @@ bool use_big(const GemmParams& p, const Knobs& kn) {
 // and stores) + K-steps x rows per step x the tile's rate, times the workgroups the fullest CU receives.  Calibrated on MI355X
 // (profiles/round2_gemm_k64.md): 4-consumer tiles take in a 128-byte operand row per 1.56 ns, 8-consumer tiles per 1.95 ns (they
 // are close to their MFMA time), 128 x 128 per 1.73 ns; fixed ~4.5 us + 0.1 ns per output element of the tile.
-inline float k64_cost(const GemmParams& p, const K64Choice& c) {
+inline float k64_cost(const GemmParams& p, const K64Choice& c, float* multi_round_loop = nullptr) {
     const int tiles_m = (p.M + c.bm - 1) / c.bm, tiles_n = (p.N + c.bn - 1) / c.bn;
     const GridPlan g = plan_grid(tiles_m, tiles_n, c.bm, c.bn);
     const float rounds = float((g.per_xcd + 31) / 32);
-    return rounds * (c.rate * (c.bm + c.bn) * (p.K / 64) + 0.1f * c.bm * c.bn) + 4500.f;
+    const float loop = rounds * c.rate * (c.bm + c.bn) * (p.K / 64);
+    if (multi_round_loop) *multi_round_loop = rounds > 1.f ? loop : 0.f;
+    return loop + rounds * 0.1f * c.bm * c.bn + 4500.f;
 }
 
 #include "gemm_fp8.hip"
@@ -1200,11 +1202,17 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
         const bool many_big_tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) >= 256;
         if (a_kc && b_kc && !kn.disable_fast && (K % 64) == 0 && kn.k64_mode != 1 && kn.shape_mode == 0 && kn.big_mode == 0 && !many_big_tiles) {
             int pick = K64_AUTO[0];
-            float best = k64_cost(p, K64_SHAPES[pick]);
+            float best_loop = 0.f;
+            float best = k64_cost(p, K64_SHAPES[pick], &best_loop);
             for (int i = 1; i < N_K64_AUTO; ++i) {
-                const float c = k64_cost(p, K64_SHAPES[K64_AUTO[i]]);
-                if (c < best) { best = c; pick = K64_AUTO[i]; }
+                float loop;
+                const float c = k64_cost(p, K64_SHAPES[K64_AUTO[i]], &loop);
+                if (c < best) { best = c; pick = K64_AUTO[i]; best_loop = loop; }
             }
+            // the per-row rates were calibrated on one-round problems whose operands stay in L2; a pick that needs several rounds is a
+            // larger problem that re-reads its panels from the Infinity Cache / HBM: measured 1.3-1.4x slower than the model (few-shot
+            // prefill: out-proj 90.8 us against 72.1 us, FFN-down 313 against 244 us on the 256 x 256 kernel) - charge it before comparing
+            best += 0.35f * best_loop;
             // round-1 256 x 256 kernel: 2.99 ns per 128-byte row and 64-deep K-step of its 512 rows, ~6 us fixed (square 4k / fc1 fwd)
             const GridPlan gb = plan_grid((M + GBM - 1) / GBM, (N + GBN - 1) / GBN, GBM, GBN);
             const float big_cost = float((gb.per_xcd + 31) / 32) * 2.99f * 512.f * (K / 64) + 6000.f;
