@@ -57,7 +57,7 @@ template <int KS>
 __device__ __forceinline__ void stage(char* rowmaj, char* /*unused*/, const bf16_t* src, int64_t ld, int row0, int n_rows,
                                       int hd, int head_off) {
     constexpr int CH = Geo<KS>::HP / 8;             // 16-byte chunks per row
-    for (int c = threadIdx.x; c < TILE * CH; c += 256) {
+    for (int c = threadIdx.x; c < TILE * CH; c += blockDim.x) {
         const int r = c / CH, ch = c - r * CH;
         uint4 val = make_uint4(0u, 0u, 0u, 0u);
         if (row0 + r < n_rows && ch * 8 < hd) val = *reinterpret_cast<const uint4*>(src + (int64_t)(row0 + r) * ld + head_off + ch * 8);
@@ -154,15 +154,19 @@ __device__ __forceinline__ bool window(Params& p, int b, int first_item, bool la
 }
 
 // ------------------------------------------------------------------------------------ forward
-template <int KS, int D16>
-__global__ __launch_bounds__(256) void fwd_kernel(Params p) {
+// NW waves = 16 NW queries per workgroup: every K / V tile a workgroup stages serves 16 NW queries, so a sequence of 257 tokens
+// (ViT-L/14) is 3 workgroups of 6 waves (18 wave slots for 17 used) instead of 5 of 4 (the fifth for ONE query row), 150 prompt
+// positions 2 of 5 instead of 3 of 4: fewer staging passes over K / V for the same products (run() picks NW per problem).
+template <int KS, int D16, int NW>
+__global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
     char* Vs = smem + Geo<KS>::ROW_BYTES;
     int* valid = reinterpret_cast<int*>(Vs + Geo<KS>::ROW_BYTES);
+    constexpr int QT = 16 * NW;
 
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
-    const int q0 = blockIdx.x * TILE;
+    const int q0 = blockIdx.x * QT;
     if (!window(p, b, q0, true)) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
     const int qi = q0 + wave * 16 + x;
@@ -181,13 +185,13 @@ __global__ __launch_bounds__(256) void fwd_kernel(Params p) {
     float m = -FLT_MAX, lsum = 0.f;
 
     int k_end = p.Sk;
-    if (p.causal) k_end = min(p.Sk, min(p.Sq, q0 + TILE) + off);
+    if (p.causal) k_end = min(p.Sk, min(p.Sq, q0 + QT) + off);
     if (k_end < 1) k_end = min(p.Sk, 1);
     for (int k0 = 0; k0 < k_end; k0 += TILE) {
         __syncthreads();
         stage<KS>(Ks, nullptr, K, p.ldk, k0, p.Sk, p.hd, head_off);
         stage<KS>(Vs, nullptr, V, p.ldv, k0, p.Sk, p.hd, head_off);
-        for (int c = threadIdx.x; c < TILE; c += 256)
+        for (int c = threadIdx.x; c < TILE; c += 64 * NW)
             valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
         __syncthreads();
         const int nf = min(4, (min(TILE, p.Sk - k0) + 15) >> 4);      // 16-key fragments of this tile that hold a key
@@ -496,8 +500,18 @@ template <int KS, int D16>
 int launch(int which, const Params& p, hipStream_t s) {
     const size_t row = Geo<KS>::ROW_BYTES;
     if (which == 0) {
-        dim3 grid((p.Sq + TILE - 1) / TILE, p.B * p.H);
-        hipLaunchKernelGGL((fwd_kernel<KS, D16>), grid, dim3(256), 2 * row + TILE * 4, s, p);
+        // waves per workgroup: the fewest wave slots for Sq queries, larger workgroups on ties (fewer passes over K / V)
+        int nw = 4, best = ((p.Sq + 63) / 64) * 4;
+        for (int cand : {5, 6, 8}) {
+            const int slots = ((p.Sq + 16 * cand - 1) / (16 * cand)) * cand;
+            if (slots <= best && p.Sq > 64) { best = slots; nw = cand; }
+        }
+        const dim3 grid((p.Sq + 16 * nw - 1) / (16 * nw), p.B * p.H);
+        const size_t lds = 2 * row + TILE * 4;
+        if (nw == 4) hipLaunchKernelGGL((fwd_kernel<KS, D16, 4>), grid, dim3(256), lds, s, p);
+        else if (nw == 5) hipLaunchKernelGGL((fwd_kernel<KS, D16, 5>), grid, dim3(320), lds, s, p);
+        else if (nw == 6) hipLaunchKernelGGL((fwd_kernel<KS, D16, 6>), grid, dim3(384), lds, s, p);
+        else hipLaunchKernelGGL((fwd_kernel<KS, D16, 8>), grid, dim3(512), lds, s, p);
     } else if (which == 1) {
         dim3 grid((p.Sq + TILE - 1) / TILE, p.B * p.H);
         hipLaunchKernelGGL((bwd_dq_kernel<KS, D16>), grid, dim3(256), 2 * row + TILE * 4, s, p);
