@@ -299,7 +299,8 @@ def attn_ref(q, k, v, key_mask, causal, scale):
     (1, 2, 577, 577, 64, False, True),   # ... with a ragged key mask (10 query / key tiles of 64, the last one 1 row deep)
     (2, 2, 70, 70, 96, True, True),      # mfma path, 3 k-steps
     (1, 2, 3, 200, 128, True, False),    # few queries against a long cache, two query-tile-free key tiles
-    (2, 1, 100, 100, 80, False, True),
+    (2, 1, 100, 100, 80, False, True),   # non-causal: 8 waves per workgroup (one 128-query tile)
+    (1, 2, 72, 72, 64, False, True),     # non-causal: 5 waves per workgroup
     (2, 8, 64, 64, 512, False, False),   # transformer mapper on OPT-6.7B (cfg5): 4096 / 8 heads, clip_length + prefix_length = 64
     (2, 8, 20, 20, 160, False, False),   # transformer mapper on GPT-2-large: 1280 / 8 heads (wide-head one-tile kernels, 2 chunks)
     (1, 2, 37, 37, 256, True, True),     # wide heads, causal + key mask
