@@ -412,7 +412,8 @@ def main():
             "metric": "mapper_train_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {w['desc']}; per-GPU batch {B}, S={S}; fwd+bwd+AdamW; random-init weights",
+            "config": {"workload": f"{args.workload}: {w['desc']}" + (f" [--mapping-type {args.mapping_type} overrides the mapper]" if args.mapping_type else "")
+                                   + f"; per-GPU batch {B}, S={S}; fwd+bwd+AdamW; random-init weights",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
                        **({"dp_exchange": {"factors": "mapper gradient factors (all-gather; whole-batch weight gradient on every rank)",
                                            "sharded": "reduce-scatter + sharded AdamW + all-gather of the bf16 operand copy",
