@@ -671,10 +671,15 @@ def test_cross_entropy_with_row_labels(ops):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,cols", [(64, 64), (130, 70), (1, 5), (12800, 640)])
+@pytest.mark.parametrize("rows,cols", [(64, 64), (130, 70), (1, 5), (12800, 640), (132, 68), (4, 4), (2048, 4096), (100, 8)])
 def test_transpose(ops, dtype, rows, cols):
     x = rnd(rows, cols, dtype=dtype, seed=1).to(DEV)
     assert torch.equal(ops.transpose(x).cpu(), x.cpu().T)
+    # a column window of a wider buffer (row stride > cols), into a wider destination
+    wide = rnd(rows, cols + 12, dtype=dtype, seed=2).to(DEV)
+    out = torch.zeros(cols, rows + 8, dtype=dtype, device=DEV)
+    ops.transpose(wide[:, 4:4 + cols], out=out[:, :rows])
+    assert torch.equal(out[:, :rows].cpu(), wide[:, 4:4 + cols].cpu().T) and bool((out[:, rows:] == 0).all())
 
 
 # --------------------------------------------------------------------------- decode-step primitives
