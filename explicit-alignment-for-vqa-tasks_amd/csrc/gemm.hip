@@ -1265,7 +1265,15 @@ extern "C" int eavqa_quantize_rows_fp8(int dtype, int rows, int cols, const void
     if (ldx % 4 || ld_out % 4 || ldx < cols || ld_out < cols) return EAVQA_E_ALIGN;
     if ((reinterpret_cast<uintptr_t>(x) & 7u) || (reinterpret_cast<uintptr_t>(out) & 3u)) return EAVQA_E_ALIGN;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == EAVQA_BF16)
+    const bool reg_ok = dtype == EAVQA_BF16 && cols % 8 == 0 && cols <= 16384 && ldx % 8 == 0 && ld_out % 8 == 0 &&
+                        !(reinterpret_cast<uintptr_t>(x) & 15u) && !(reinterpret_cast<uintptr_t>(out) & 7u);
+    if (reg_ok) {
+        const int nv = (cols / 8 + 255) / 256;
+#define EAVQA_QR(NV) hipLaunchKernelGGL(quantize_rows_fp8_reg_kernel<NV>, dim3(rows), dim3(256), 0, s, cols, reinterpret_cast<const bf16_t*>(x), \
+                                        ldx, reinterpret_cast<unsigned char*>(out), ld_out, row_scale)
+        if (nv <= 1) EAVQA_QR(1); else if (nv <= 2) EAVQA_QR(2); else if (nv <= 4) EAVQA_QR(4); else EAVQA_QR(8);
+#undef EAVQA_QR
+    } else if (dtype == EAVQA_BF16)
         hipLaunchKernelGGL(quantize_rows_fp8_kernel<bf16_t>, dim3(rows), dim3(256), 0, s, cols, reinterpret_cast<const bf16_t*>(x), ldx,
                            reinterpret_cast<unsigned char*>(out), ld_out, row_scale);
     else if (dtype == EAVQA_F32)

@@ -148,3 +148,42 @@ __global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(int cols, const 
         *reinterpret_cast<int*>(o + c) = pk;
     }
 }
+
+// bf16 rows of up to 2048 NV elements, 16-byte aligned: the row stays in registers between the amax pass and the conversion (one
+// read of x, 16-byte loads, 8-byte stores); same arithmetic as the kernel above, so the bytes are identical.
+template <int NV>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_reg_kernel(int cols, const bf16_t* __restrict__ x, int64_t ldx, unsigned char* __restrict__ out,
+                                                                    int64_t ld_out, float* __restrict__ row_scale) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bf16_t* xr = x + (int64_t)row * ldx;
+    bf16x8 v[NV];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (tid + 256 * i) * 8;
+        v[i] = (bf16x8){};
+        if (c < cols) v[i] = *reinterpret_cast<const bf16x8*>(xr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf((float)v[i][e]));
+    }
+    amax = wave_max(amax);
+    if ((tid & 63) == 0) red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+    const float inv = 1.f / scale;
+    if (tid == 0) row_scale[row] = scale;
+    unsigned char* o = out + (int64_t)row * ld_out;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (tid + 256 * i) * 8;
+        if (c < cols) {
+            int lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][0] * inv, (float)v[i][1] * inv, 0, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][2] * inv, (float)v[i][3] * inv, lo, true);
+            int hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][4] * inv, (float)v[i][5] * inv, 0, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32((float)v[i][6] * inv, (float)v[i][7] * inv, hi, true);
+            *reinterpret_cast<int2*>(o + c) = make_int2(lo, hi);
+        }
+    }
+}

@@ -38,7 +38,7 @@ def quant_ref(x):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("rows,cols", [(1, 128), (7, 4096), (33, 16384), (70, 1280), (3, 12)])
+@pytest.mark.parametrize("rows,cols", [(1, 128), (7, 4096), (33, 16384), (70, 1280), (3, 12), (5, 8192), (4, 20480), (9, 2056)])
 def test_quantize_rows_matches_torch_e4m3fn(dtype, rows, cols):
     from eavqa_amd import ops
     x = rnd(rows, cols, seed=rows, scale=3.0, dtype=dtype)
