@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--fp8", action="store_true", help="frozen LM in fp8 (cfg5): only the bf16 GEMMs (mapper, CLIP tower) are listed")
     ap.add_argument("--vit", default=None, help="time the GEMMs of a CLIP encode instead (e.g. ViT-L/14), --images per call")
     ap.add_argument("--images", type=int, default=160)
     a = ap.parse_args()
@@ -33,7 +34,7 @@ def main():
                 pass
         stepper = _S()
         return analyse(stepper, a, dev)
-    w, vcfg, lcfg, vit, model, opt, batch, pad = bench.build_workload(a.workload, torch.bfloat16, dev, 0)
+    w, vcfg, lcfg, vit, model, opt, batch, pad = bench.build_workload(a.workload, torch.bfloat16, dev, 0, weight_format="fp8" if a.fp8 else "native")
     from eavqa_amd.trainers.data_parallel import GradSync
     stepper = bench.Stepper(vit, model, opt, batch, pad, GradSync(model.clip_project.flat.grad, 1), overlap_vit=False)
     return analyse(stepper, a, dev)
