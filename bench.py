@@ -523,7 +523,8 @@ def gemm_roofline(stepper, ops, workload="cfg2", dtype_name="bf16"):
         with open(tfile) as f:
             t = json.load(f)
         if t.get("gemm_source_digest") == gemm_source_digest():
-            traffic, traffic_source = round(t["bytes_per_launch"]), f"profiles/{os.path.basename(tfile)} @ gemm sources {t['gemm_source_digest']}"
+            fam = t.get("families", {}).get(main_kind, t)            # the dominant kernel's own launches (fp8 / bf16), not the mix
+            traffic, traffic_source = round(fam["bytes_per_launch"]), f"profiles/{os.path.basename(tfile)} @ gemm sources {t['gemm_source_digest']}"
         else:
             traffic_source = f"dropped: {os.path.basename(tfile)} was measured on gemm sources {t.get('gemm_source_digest')}, this run is {gemm_source_digest()}"
     kernel = ("eavqa_gemm_fp8: gemm_fp8_k128s_kernel (v_mfma_scale_f32_16x16x128_f8f6f4, loader / consumer specialised full-line tiles)"

@@ -36,7 +36,16 @@ h = hashlib.sha256()
 for f_ in ("gemm.hip", "gemm_k64.hip", "gemm_fp8.hip", "common.h"):
     with open(os.path.join(ROOT, "explicit-alignment-for-vqa-tasks_amd", "csrc", f_), "rb") as fh:
         h.update(fh.read())
-res = dict(gemm_source_digest=h.hexdigest()[:12], counter_units="KiB", fetch_correction="x2 (gfx950 wide coalesced reads, MI355X_MICROARCH.md HBM section)",
+# per operand format: a step of the fp8 workload launches fp8 GEMMs (frozen LM) AND bf16 GEMMs (mapper, CLIP tower)
+families = {}
+for fam in ("fp8", "bf16", "f32"):
+    ff = sum(sum(F[k]) for k in F if "gemm_" + fam in k)
+    fw = sum(sum(W.get(k, [])) for k in F if "gemm_" + fam in k)
+    fn = sum(len(F[k]) for k in F if "gemm_" + fam in k)
+    if fn:
+        families[fam] = dict(gemm_launches=fn, bytes_per_launch=(2 * ff + fw) * 1024 / fn, read_bytes_per_launch=2 * ff * 1024 / fn,
+                             write_bytes_per_launch=fw * 1024 / fn)
+res = dict(gemm_source_digest=h.hexdigest()[:12], families=families, counter_units="KiB", fetch_correction="x2 (gfx950 wide coalesced reads, MI355X_MICROARCH.md HBM section)",
            gemm_launches=n, bytes_per_launch=(2 * tot_f + tot_w) * 1024 / max(n, 1),
            read_bytes_per_launch=2 * tot_f * 1024 / max(n, 1), write_bytes_per_launch=tot_w * 1024 / max(n, 1), kernels=rows)
 json.dump(res, open(out, "w"), indent=1)
