@@ -80,3 +80,19 @@ def test_cpu_tensors_are_rejected_not_emulated():
     from eavqa_amd import ops, _lib
     with pytest.raises(_lib.EavqaError, match="no CPU fallback"):
         ops.gemm(torch.zeros(8, 8), torch.zeros(8, 8))
+
+
+def test_decode_plans_are_pure_host_arithmetic(lib):
+    """eavqa_gemm_splitk_plan / eavqa_lm_block_workspace_bytes touch no device: the split of every decode GEMM of the few-shot model
+    (OPT-2.7B, B = 32) is the one profiles/round2_decode.md was measured with, unsupported shapes give 0."""
+    plan = lib.eavqa_gemm_splitk_plan
+    E, F = 2560, 10240
+    assert [plan(32, 3 * E, E), plan(32, E, E), plan(32, F, E), plan(32, E, F)] == [4, 10, 4, 10]
+    for M, N, K in ((32, 3 * E, E), (1, 64, 32), (64, 50272, 2560), (17, 200, 96), (64, 12800, 512)):
+        ks = plan(M, N, K)
+        assert ks >= 1 and K % (32 * ks) == 0 and (K // ks) * (1 if M <= 16 else 2 if M <= 32 else 4) * 32 <= 64 * 1024
+    assert plan(65, 128, 64) == 0 and plan(8, 128, 48) == 0 and plan(0, 128, 64) == 0
+    ws = lib.eavqa_lm_block_workspace_bytes
+    small, big = ws(1, 32, E, F), ws(1, 4800, E, F)             # dtype 1 = bfloat16: a decode step, the 150-position prefill of 32 prompts
+    assert 0 < small < big
+    assert 0 < ws(0, 32, E, F) < small            # fp32 has no split-K decode route: no partial-sum buffers in its workspace
