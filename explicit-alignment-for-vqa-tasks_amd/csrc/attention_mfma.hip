@@ -187,41 +187,93 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
     int k_end = p.Sk;
     if (p.causal) k_end = min(p.Sk, min(p.Sq, q0 + QT) + off);
     if (k_end < 1) k_end = min(p.Sk, 1);
+    // K / V tiles travel global -> registers -> LDS; the loads of tile t + 1 are issued before the products of tile t and written to
+    // LDS after them, so their latency runs under the MFMA / softmax work instead of in front of it
+    constexpr int CH = Geo<KS>::HP / 8, NT = 64 * NW, NCH = (TILE * CH + NT - 1) / NT;
+    uint4 kreg[NCH], vreg[NCH];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = threadIdx.x + i * NT, r = c / CH, ch = c - r * CH;
+            kreg[i] = make_uint4(0u, 0u, 0u, 0u);
+            vreg[i] = kreg[i];
+            if (c < TILE * CH && k0 + r < p.Sk && ch * 8 < p.hd) {
+                kreg[i] = *reinterpret_cast<const uint4*>(K + (int64_t)(k0 + r) * p.ldk + head_off + ch * 8);
+                vreg[i] = *reinterpret_cast<const uint4*>(V + (int64_t)(k0 + r) * p.ldv + head_off + ch * 8);
+            }
+        }
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = threadIdx.x + i * NT, r = c / CH, ch = c - r * CH;
+            if (c < TILE * CH) {
+                *reinterpret_cast<uint4*>(Ks + r * Geo<KS>::PR + ch * 16) = kreg[i];
+                *reinterpret_cast<uint4*>(Vs + r * Geo<KS>::PR + ch * 16) = vreg[i];
+            }
+        }
+    };
+    gload(0);
     for (int k0 = 0; k0 < k_end; k0 += TILE) {
-        __syncthreads();
-        stage<KS>(Ks, nullptr, K, p.ldk, k0, p.Sk, p.hd, head_off);
-        stage<KS>(Vs, nullptr, V, p.ldv, k0, p.Sk, p.hd, head_off);
-        for (int c = threadIdx.x; c < TILE; c += 64 * NW)
+        __syncthreads();                                               // the previous tile is consumed
+        lstore();
+        for (int c = threadIdx.x; c < TILE; c += NT)
             valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
         __syncthreads();
+        if (k0 + TILE < k_end) gload(k0 + TILE);
         const int nf = min(4, (min(TILE, p.Sk - k0) + 15) >> 4);      // 16-key fragments of this tile that hold a key
         if (wave_has_query) {
         f32x4 st[4];
         tile_dot<KS>(st, Ks, qf, x, g, nf);
-        float tmax = -FLT_MAX;
+        // a full tile without a mask (every tile but the last of the CLIP tower's 257 tokens): no per-key tests, and the scale moves
+        // into the exponent - exp((s - m) scale) = exp2(s c - m c'), two instructions per score instead of ten
+        const bool plain_tile = !p.causal && !p.key_mask && k0 + TILE <= p.Sk && p.scale > 0.f;
+        float m_new;
+        if (plain_tile) {
+            float tmax = -FLT_MAX;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kk = 16 * f + 4 * g + r;          // key within the tile
-                const bool exists = k0 + kk < p.Sk;
-                const bool vis = valid[kk] && (!p.causal || (k0 + kk) <= qi + off);
-                st[f][r] = exists ? (vis ? st[f][r] * p.scale : -FLT_MAX) : -INFINITY;
-                tmax = fmaxf(tmax, st[f][r]);
-            }
-        const float m_new = fmaxf(m, group4_max(tmax));
+                for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[f][r]);
+            m_new = fmaxf(m, group4_max(tmax) * p.scale);
+        } else {
+            float tmax = -FLT_MAX;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kk = 16 * f + 4 * g + r;          // key within the tile
+                    const bool exists = k0 + kk < p.Sk;
+                    const bool vis = valid[kk] && (!p.causal || (k0 + kk) <= qi + off);
+                    st[f][r] = exists ? (vis ? st[f][r] * p.scale : -FLT_MAX) : -INFINITY;
+                    tmax = fmaxf(tmax, st[f][r]);
+                }
+            m_new = fmaxf(m, group4_max(tmax));
+        }
         const float corr = __expf(m - m_new);
         lsum *= corr;
 #pragma unroll
         for (int dm = 0; dm < D16; ++dm) { acc[dm][0] *= corr; acc[dm][1] *= corr; acc[dm][2] *= corr; acc[dm][3] *= corr; }
+        if (plain_tile) {
+            const float c2 = p.scale * 1.4426950408889634f, mm = m_new * 1.4426950408889634f;
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+            for (int f = 0; f < 4; ++f)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pj = __expf(st[f][r] - m_new);      // exp(-inf) = 0 for keys that do not exist
-                st[f][r] = pj;
-                lsum += pj;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const float pj = __builtin_amdgcn_exp2f(fmaf(st[f][r], c2, -mm));
+                    st[f][r] = pj;
+                    lsum += pj;
+                }
+        } else {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pj = __expf(st[f][r] - m_new);      // exp(-inf) = 0 for keys that do not exist
+                    st[f][r] = pj;
+                    lsum += pj;
+                }
+        }
         tile_accumulate<KS, D16>(acc, Vs, st, x, g, nf);
         m = m_new;
         }
