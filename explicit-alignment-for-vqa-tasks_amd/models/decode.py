@@ -95,9 +95,12 @@ def _block(lm: FrozenCausalLM, cache: _KVCache, x: Tensor, mask: Tensor, B: int,
     """All decoder layers for ``Sq`` new positions per row starting at sequence index ``row0`` (one C call): K/V of the
     new positions are appended to the cache and attention runs against rows [0, row0+Sq).  ``x`` is updated in place."""
     c = lm.cfg
-    _lib.call("eavqa_lm_block_forward", ops.dtype_id(lm.dtype), len(lm.layers), cache.table, c.n_embd, c.n_head, c.ffn,
-              _lib.ACT[c.act], float(c.eps), B, Sq, row0, S_max, x.data_ptr(), mask.data_ptr(), mask.stride(0), cache.ws.data_ptr(),
-              cache.ws_bytes, ops._stream())
+    args = (ops.dtype_id(lm.dtype), len(lm.layers), cache.table, c.n_embd, c.n_head, c.ffn, _lib.ACT[c.act], float(c.eps), B, Sq, row0, S_max,
+            x.data_ptr(), mask.data_ptr(), mask.stride(0), cache.ws.data_ptr(), cache.ws_bytes, ops._stream())
+    if ops.KernelSelect.decode_route:
+        _lib.call("eavqa_lm_block_forward_ex", *args, ops.KernelSelect.decode_route)
+    else:
+        _lib.call("eavqa_lm_block_forward", *args)
     return x
 
 

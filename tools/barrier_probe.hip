@@ -56,6 +56,24 @@ __global__ __launch_bounds__(512) void exchange(unsigned* counter, int rounds, u
     if (bad) atomicAdd(fail, bad);
 }
 
+// MODE 2 barrier (no fences), but every exchanged word is written / read with an agent-scope relaxed ATOMIC store / load (sc1: served at
+// the level all XCDs share): is that a correct and cheap hand-over?
+__global__ __launch_bounds__(512) void exchange_atomic(unsigned* counter, int rounds, unsigned* buf, unsigned* fail) {
+    const unsigned nb = gridDim.x, me = blockIdx.x;
+    unsigned bad = 0;
+    for (int r = 1; r <= rounds; ++r) {
+        unsigned* mine = buf + ((size_t)(r & 1) * nb + me) * 1024;
+        for (int i = threadIdx.x; i < 1024; i += blockDim.x)
+            __hip_atomic_store(mine + i, (unsigned)r * 0x10001u + me * 7u + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!grid_barrier<2>(counter, (unsigned)r * nb)) { if (threadIdx.x == 0) atomicAdd(fail, 1u << 16); return; }
+        const unsigned other = (me + 37u) % nb;
+        const unsigned* theirs = buf + ((size_t)(r & 1) * nb + other) * 1024;
+        for (int i = threadIdx.x; i < 1024; i += blockDim.x)
+            if (__hip_atomic_load(theirs + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned)r * 0x10001u + other * 7u + i) ++bad;
+    }
+    if (bad) atomicAdd(fail, bad);
+}
+
 template <int MODE>
 int run(const char* name, unsigned* counter, unsigned* fail, unsigned* buf, int nb) {
     hipEvent_t e0, e1;
@@ -96,6 +114,23 @@ int main() {
     if (hipExtMallocWithFlags((void**)&fbuf, (size_t)2 * nb * 1024 * 4, hipDeviceMallocFinegrained) == hipSuccess) {
         if (run<2>("no fences, FINE-GRAINED buffer", counter, fail, fbuf, nb)) return 1;
     } else printf("hipDeviceMallocFinegrained not available\n");
+    {
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int rounds : {64, 256}) {
+            CK(hipMemset(counter, 0, 4)); CK(hipMemset(fail, 0, 4));
+            void* args[] = {&counter, (void*)&rounds, &buf, &fail};
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0));
+            CK(hipLaunchCooperativeKernel(reinterpret_cast<const void*>(exchange_atomic), dim3(nb), dim3(512), args, 0, 0));
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            unsigned f; CK(hipMemcpy(&f, fail, 4, hipMemcpyDeviceToHost));
+            printf("%-34s %-9s rounds=%4d  %8.1f us total  %6.2f us per barrier  failures=%u\n", "no fences, ATOMIC word exchange", "exchange", rounds,
+                   ms * 1e3, ms * 1e3 / rounds, f);
+        }
+    }
     printf("done\n");
     return 0;
 }
