@@ -1198,8 +1198,13 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
         // Default dispatch (K % 64 == 0): the loader / consumer specialised full-line tile the cost model ranks first, or the
         // round-1 256 x 256 kernel where the model says its 1/128 B-per-FLOP intensity wins (problems with hundreds of such tiles:
         // the CLIP tower, few-shot prefill, lm_head forward).  M <= 64 weight-streaming shapes take the same route.
-        // Problems with more than one 256 x 256 tile per CU keep the round-1 dispatcher below (calibrated on exactly those shapes).
-        const bool many_big_tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN) >= 256;
+        // Problems of four and more rounds of 256 x 256 tiles, or of more than 96 tile rows (the CLIP tower at 160 images: M = 41 120),
+        // keep the round-1 dispatcher below, calibrated on exactly those shapes; 2-3 rounds at moderate M (few-shot prefill, M = 4 800)
+        // are ranked here, where round quantisation decides: 570 tiles are 3 rounds of the 256 x 256 kernel but 3.6 of 256 x 160
+        // (measured 177 against 215 us on the QKV projection; the grid of tools/dispatch_calib.py is the evidence for both limits).
+        const GridPlan gbig = plan_grid((M + GBM - 1) / GBM, (N + GBN - 1) / GBN, GBM, GBN);
+        const int big_rounds = (gbig.per_xcd + 31) / 32;
+        const bool many_big_tiles = big_rounds >= 4 || (big_rounds >= 2 && (M + GBM - 1) / GBM > 96);
         if (a_kc && b_kc && !kn.disable_fast && (K % 64) == 0 && kn.k64_mode != 1 && kn.shape_mode == 0 && kn.big_mode == 0 && !many_big_tiles) {
             int pick = K64_AUTO[0];
             float best_loop = 0.f;
@@ -1213,9 +1218,10 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
             // larger problem that re-reads its panels from the Infinity Cache / HBM: measured 1.3-1.4x slower than the model (few-shot
             // prefill: out-proj 90.8 us against 72.1 us, FFN-down 313 against 244 us on the 256 x 256 kernel) - charge it before comparing
             best += 0.35f * best_loop;
-            // round-1 256 x 256 kernel: 2.99 ns per 128-byte row and 64-deep K-step of its 512 rows, ~6 us fixed (square 4k / fc1 fwd)
-            const GridPlan gb = plan_grid((M + GBM - 1) / GBM, (N + GBN - 1) / GBN, GBM, GBN);
-            const float big_cost = float((gb.per_xcd + 31) / 32) * 2.99f * 512.f * (K / 64) + 6000.f;
+            // round-1 256 x 256 kernel: 2.99 ns per 128-byte row and 64-deep K-step of its 512 rows, ~6 us fixed (square 4k / fc1 fwd);
+            // the same multi-round charge (3 rounds on the prefill QKV shape: 215 us measured against 190 modelled)
+            const float big_loop = float(big_rounds) * 2.99f * 512.f * (K / 64);
+            const float big_cost = big_loop * (big_rounds > 1 ? 1.35f : 1.f) + 6000.f;
             if (M > 64 && big_cost < best) return launch_big(p, s);
             return K64_SHAPES[pick].launch(p, s);
         }
