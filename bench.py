@@ -12,9 +12,13 @@ all-reduce (RCCL, N > 1) -> fused AdamW.  Inputs are resident in HBM before the 
 Rank 0 prints ONE JSON line (contract in the task description) that also carries
   roofline     - achieved TFLOP/s of the dominant kernel (the MFMA GEMM) from HIP events recorded on
                  the launch stream around every GEMM launch of an extra, instrumented step that
-                 runs right after the timed region (so the timed value is not perturbed), and
+                 runs right after the timed region (so the timed value is not perturbed), plus the
+                 HBM-bound ops of that step (bytes / duration / 8 TB/s) under roofline.hbm_kernels,
   cpu_baseline - the CPU oracle (oracle/ref_cpu.py, kind "port") timed on this host's cores on a
-                 bounded sample of the same workload (N = 1, rank 0 only).
+                 bounded sample of the same workload (N = 1, rank 0 only), and
+  extra        - (default cfg2 run, N = 1) a list of the other 1-GPU BASELINE configs, each in the same shape:
+                 few-shot VQA2 generate (cfg4, questions/s, per-phase roofline), cfg3 bf16 and cfg5 fp8 training
+                 (5 warm-up + 10 timed steps each, own roofline).
 """
 from __future__ import annotations
 
@@ -150,6 +154,11 @@ class Stepper:
         if self.side is not None:
             torch.cuda.current_stream().wait_stream(self.side)
 
+    def exchange_ms(self):
+        """Device time of the last step's gradient exchange (HIP events on the exchange's own stream), None when there is none."""
+        fn = getattr(self.sync, "last_exchange_ms", None)
+        return fn() if fn is not None else None
+
 
 FEWSHOT = dict(vit="ViT-L/14", lm="facebook/opt-2.7b", prefix_length=10, batch=32, shots=4, seg_len=20, new_tokens=10,
                desc="few-shot VQA2 generate (BASELINE configs[3]): CLIP ViT-L/14 + OPT-2.7B, 4 in-context shots + query "
@@ -229,7 +238,7 @@ def fewshot_qps(dtype, device, reps=3):
     del model, lm, vit
     torch.cuda.empty_cache()
     return {"metric": "fewshot_vqa_questions_per_sec", "value": round(B / dt, 2), "unit": "questions/s", "ms_per_batch": round(dt * 1e3, 2),
-            "config": {"workload": f["desc"], "batch": B, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "kv_cache": True},
+            "config": {"workload": "few-shot cfg4: " + f["desc"], "batch": B, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "kv_cache": True},
             "roofline": roof}
 
 
@@ -294,48 +303,20 @@ def host_threads() -> int:
     return max(1, min(n, int(os.environ.get("EAVQA_CPU_THREADS", "16"))))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
-                    help="fp8: bf16 activations, the frozen LM's Linear weights in e4m3 on the block-scaled MFMA (cfg5)")
-    ap.add_argument("--cpu-baseline-samples", type=int, default=64, help="0 disables the CPU baseline leg (default: one whole step of the workload, ~10 s)")
-    ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--dp-exchange", choices=["auto", "factors", "allreduce", "sharded"], default="auto",
-                    help="N > 1: 'factors' all-gathers the MLP mapper's gradient factors, 'sharded' = reduce-scatter + sharded AdamW + "
-                         "all-gather, 'allreduce' = flat gradient all-reduce; 'auto' takes the cheapest under the cost model of "
-                         "eavqa_amd.trainers.optim.choose_dp_exchange (DESIGN.md section 7)")
-    ap.add_argument("--mapping-type", choices=["mlp", "transformer"], default=None, help="override the workload's mapper")
-    ap.add_argument("--no-overlap", action="store_true", help="run the CLIP encode on the main stream (no cross-step pipelining)")
-    ap.add_argument("--no-fewshot", action="store_true", help="skip the few-shot generate leg (metric M2, reported under 'extra')")
-    args = ap.parse_args()
+def train_leg(workload, dtype_name, steps, warmup, rank, world, device, args, log_prefix=""):
+    """One training workload: build, ``warmup`` untimed steps, exactly ``steps`` timed steps between barriers (max over ranks),
+    then - behind the timed region - the instrumented roofline step.  Returns the JSON object of the leg (no cpu_baseline / extra)."""
+    from eavqa_amd import ops
+    from eavqa_amd.trainers.data_parallel import GradSync
+    from eavqa_amd.trainers.optim import ShardedAdamW, choose_dp_exchange, dp_exchange_costs
 
-    from eavqa_amd import _lib, ops
-    from eavqa_amd.trainers.data_parallel import GradSync, init_from_env
-
-    rank, local, world = init_from_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP extension is the only compute path")
-    # EAVQA_FORCE_DEVICE: rehearse the N > 1 path on a one-GPU box (all ranks on one card, gloo backend)
-    dev_index = int(os.environ.get("EAVQA_FORCE_DEVICE", local))
-    torch.cuda.set_device(dev_index)
-    device = f"cuda:{dev_index}"
-    if _lib.load().eavqa_check_device() != 0:
-        raise SystemExit("device is not gfx950")
-    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
-    weight_format = "fp8" if args.dtype == "fp8" else "native"
-
-    log(f"building workload {args.workload} ({args.dtype}) on {device}")
-    w, vcfg, lcfg, vit, model, opt, batch, pad = build_workload(args.workload, dtype, device, rank, args.mapping_type, weight_format)
+    dtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
+    weight_format = "fp8" if dtype_name == "fp8" else "native"
+    log(f"{log_prefix}building workload {workload} ({dtype_name}) on {device}")
+    w, vcfg, lcfg, vit, model, opt, batch, pad = build_workload(workload, dtype, device, rank, args.mapping_type, weight_format)
     torch.cuda.synchronize()
-    log("workload built")
+    log(f"{log_prefix}workload built")
     # N > 1: which exchange carries the mapper gradient (DESIGN.md section 7)
-    from eavqa_amd.trainers.optim import ShardedAdamW, choose_dp_exchange
     flat = model.clip_project.flat
     has_factors = hasattr(model.clip_project, "dp_factor_exchange")
     exchange = args.dp_exchange
@@ -362,68 +343,135 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         stepper.step()
         if i == 0:
             torch.cuda.synchronize()
-            log("first step done")
+            log(f"{log_prefix}first step done")
     stepper.flush()
     barrier()
-    log("warmup done")
+    log(f"{log_prefix}warmup done")
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = stepper.step()
     stepper.flush()
     barrier()
     dt = time.perf_counter() - t0
-    log(f"timed region: {args.steps} steps in {dt:.3f} s")
+    log(f"{log_prefix}timed region: {steps} steps in {dt:.3f} s")
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     B, S = w["batch"], w["prefix_length"] + batch["input_ids"].shape[1]
-    value = world * B * args.steps / dt
+    value = world * B * steps / dt
+    ms_per_step = 1e3 * dt / steps
 
     roof = None
     if not args.no_roofline:
-        roof = gemm_roofline(stepper, ops, args.workload, args.dtype)      # every rank runs it (the step contains the all-reduce); rank 0 reports
+        # every rank runs it (the step contains the exchange); rank 0 reports
+        roof = step_roofline(vit, model, opt, batch, pad, sync, ops, workload, dtype_name, ms_per_step, getattr(args, "hbm_bytes_out", None))
         if rank == 0:
-            log(f"roofline pass done: {roof}")
-    extra = None
-    if rank == 0 and world == 1 and not args.no_fewshot:
-        del stepper, vit, model, opt          # free the training workload's HBM first
-        torch.cuda.empty_cache()
+            log(f"{log_prefix}roofline pass done: {roof}")
+    fps = flops_per_sample(vcfg, lcfg, w["prefix_length"], S, vcfg.proj, w["mapping_type"], w.get("clip_length", w["prefix_length"]))
+    dist_cfg = {}
+    if world > 1:
+        import torch.distributed as dist
+        dist_cfg = {"world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                    "dp_exchange": {"factors": "mapper gradient factors (all-gather; whole-batch weight gradient on every rank)",
+                                    "sharded": "reduce-scatter + sharded AdamW + all-gather of the bf16 operand copy",
+                                    "allreduce": "flat gradient all-reduce"}[exchange],
+                    # MODELLED, never measured on a multi-GPU box: what the chooser compared
+                    "dp_exchange_model_ms_unmeasured": {k: round(v * 1e3, 2) for k, v in dp_exchange_costs(
+                        flat.numel, flat.numel if has_factors else 0, w["batch"], world).items()},
+                    "dp_exchange_ms_per_step": stepper.exchange_ms()}
+    line = {
+        "metric": "mapper_train_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
+        "config": {"workload": f"{workload}: {w['desc']}" + (f" [--mapping-type {args.mapping_type} overrides the mapper]" if args.mapping_type else "")
+                               + f"; per-GPU batch {B}, S={S}; fwd+bwd+AdamW; random-init weights",
+                   "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}", **dist_cfg,
+                   "algorithmic_gflop_per_sample": round(fps / 1e9, 1),
+                   "step_tflops": round(value * fps / 1e12, 1), "final_loss": round(float(loss.item()), 4)},
+        "roofline": roof,
+    }
+    del stepper, vit, model, opt, sync, batch          # free the workload's HBM before the next leg
+    torch.cuda.empty_cache()
+    return line
+
+
+# secondary legs carried under "extra" by the default run (N = 1): the other 1-GPU BASELINE configs, short
+EXTRA_TRAIN_LEGS = (("cfg3", "bf16", 10, 5), ("cfg5", "fp8", 10, 5))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "fp8"],
+                    help="fp8: bf16 activations, the frozen LM's Linear weights in e4m3 on the block-scaled MFMA (cfg5)")
+    ap.add_argument("--cpu-baseline-samples", type=int, default=64, help="0 disables the CPU baseline leg (default: one whole step of the workload, ~10 s)")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dp-exchange", choices=["auto", "factors", "allreduce", "sharded"], default="auto",
+                    help="N > 1: 'factors' all-gathers the MLP mapper's gradient factors, 'sharded' = reduce-scatter + sharded AdamW + "
+                         "all-gather, 'allreduce' = flat gradient all-reduce; 'auto' takes the cheapest under the cost model of "
+                         "eavqa_amd.trainers.optim.choose_dp_exchange (DESIGN.md section 7)")
+    ap.add_argument("--mapping-type", choices=["mlp", "transformer"], default=None, help="override the workload's mapper")
+    ap.add_argument("--no-overlap", action="store_true", help="run the CLIP encode on the main stream (no cross-step pipelining)")
+    ap.add_argument("--no-fewshot", action="store_true", help="skip the few-shot generate leg (metric M2, reported under 'extra')")
+    ap.add_argument("--no-extra-train", action="store_true",
+                    help="skip the short cfg3 (bf16) and cfg5 (fp8) training legs that the default cfg2 run reports under 'extra'")
+    ap.add_argument("--hbm-bytes-out", default=None,
+                    help="write the algorithmic bytes per launch of the HBM-bound ops of one step as JSON (input of tools/round_profile_report.py)")
+    args = ap.parse_args()
+
+    from eavqa_amd import _lib
+    from eavqa_amd.trainers.data_parallel import init_from_env
+
+    rank, local, world = init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP extension is the only compute path")
+    # EAVQA_FORCE_DEVICE: rehearse the N > 1 path on a one-GPU box (all ranks on one card, gloo backend)
+    dev_index = int(os.environ.get("EAVQA_FORCE_DEVICE", local))
+    torch.cuda.set_device(dev_index)
+    device = f"cuda:{dev_index}"
+    if _lib.load().eavqa_check_device() != 0:
+        raise SystemExit("device is not gfx950")
+    dtype = torch.float32 if args.dtype == "f32" else torch.bfloat16
+
+    line = train_leg(args.workload, args.dtype, args.steps, args.warmup, rank, world, device, args)
+
+    extra = []
+    solo = rank == 0 and world == 1
+    if solo and not args.no_fewshot:
         try:
             log("few-shot generate leg ...")
-            extra = fewshot_qps(dtype, device)
-            log(f"few-shot leg done: {extra}")
-        except Exception as e:                # never lose the headline line to the secondary metric
-            extra = {"metric": "fewshot_vqa_questions_per_sec", "error": repr(e)[:300]}
+            extra.append(fewshot_qps(dtype, device))
+            log(f"few-shot leg done: {extra[-1]}")
+        except Exception as e:                # never lose the headline line to a secondary metric
+            extra.append({"metric": "fewshot_vqa_questions_per_sec", "error": repr(e)[:300]})
+    if solo and not args.no_extra_train and args.workload == "cfg2" and args.dtype == "bf16" and not args.mapping_type:
+        for name, dt_name, k, wu in EXTRA_TRAIN_LEGS:
+            try:
+                leg_args = argparse.Namespace(**{**vars(args), "hbm_bytes_out": None})
+                extra.append(train_leg(name, dt_name, k, wu, rank, world, device, leg_args, log_prefix=f"[{name} {dt_name}] "))
+            except Exception as e:
+                extra.append({"metric": "mapper_train_samples_per_sec", "config": {"workload": name}, "dtype": dt_name, "error": repr(e)[:300]})
+                torch.cuda.empty_cache()
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_baseline_samples > 0:
+    if solo and args.cpu_baseline_samples > 0:
         log(f"cpu baseline on {host_threads()} threads ...")
         cpu = cpu_baseline(args.workload, args.cpu_baseline_samples, host_threads())
         log(f"cpu baseline done: {cpu}")
 
     if rank == 0:
-        fps = flops_per_sample(vcfg, lcfg, w["prefix_length"], S, vcfg.proj, w["mapping_type"], w.get("clip_length", w["prefix_length"]))
-        line = {
-            "metric": "mapper_train_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {w['desc']}" + (f" [--mapping-type {args.mapping_type} overrides the mapper]" if args.mapping_type else "")
-                                   + f"; per-GPU batch {B}, S={S}; fwd+bwd+AdamW; random-init weights",
-                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}",
-                       **({"dp_exchange": {"factors": "mapper gradient factors (all-gather; whole-batch weight gradient on every rank)",
-                                           "sharded": "reduce-scatter + sharded AdamW + all-gather of the bf16 operand copy",
-                                           "allreduce": "flat gradient all-reduce"}[exchange],
-                           "dp_exchange_model_ms": {k: round(v * 1e3, 2) for k, v in __import__("eavqa_amd.trainers.optim", fromlist=["x"]).dp_exchange_costs(
-                               flat.numel, flat.numel if has_factors else 0, w["batch"], world).items()}} if world > 1 else {}),
-                       "algorithmic_gflop_per_sample": round(fps / 1e9, 1),
-                       "step_tflops": round(value * fps / 1e12, 1), "final_loss": round(float(loss.item()), 4)},
-            "roofline": roof, "cpu_baseline": cpu, "extra": extra,
-        }
+        line["cpu_baseline"] = cpu
+        line["extra"] = extra or None
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
@@ -441,13 +489,58 @@ def gemm_source_digest():
     return h.hexdigest()[:12]
 
 
-def gemm_roofline(stepper, ops, workload="cfg2", dtype_name="bf16"):
-    """HIP events (torch.cuda.Event records on the current stream = the stream eavqa_gemm launches on) around every
-    GEMM launch of one extra step: achieved = algorithmic FLOPs per launch / average launch duration.  With --dtype fp8 the
-    dominant kernel is the fp8 GEMM (eavqa_gemm_fp8, priced against the 5 PFLOP/s dense fp8 peak); the bf16 launches of that run
-    (mapper, CLIP tower) are reported beside it."""
-    real, real8 = ops.gemm, ops.gemm_fp8
+# HBM-bound ops of a step: (ops attribute, rocprof kernel-name pattern, algorithmic bytes of one call).  Bytes = every operand read once and
+# every result written once; the patterns join this table with a rocprofv3 kernel-stats CSV in
+# tools/round_profile_report.py.
+def _hbm_models():
+    es = lambda t: t.element_size()
+
+    def ln_fwd(x, gamma, beta, eps, out_dtype, save_stats=False, out=None):
+        rows, cols = x.shape
+        return rows * cols * (es(x) + torch.empty(0, dtype=out_dtype).element_size()) + (8 * rows if save_stats else 0)
+
+    def ln_bwd(x, dy, gamma, mean, rstd, dres=None, dgamma=None, dbeta=None, out=None, lowp_out=None):
+        rows, cols = x.shape
+        return rows * cols * (es(x) + es(dy) + (4 if dres is not None else 0) + 4 + (es(lowp_out) if lowp_out is not None else 0)) + 8 * rows
+
+    def ce_fwd(logits, labels, V):
+        return logits.shape[0] * V * 4
+
+    def ce_bwd(logits, labels, V, row_lse, count, gscale, dtype, ldd):
+        return logits.shape[0] * (V * 4 + ldd * torch.empty(0, dtype=dtype).element_size())
+
+    def adamw(param, grad, m, v, *a, shadow=None, **k):
+        return param.numel() * (28 + (es(shadow) if shadow is not None else 0))      # p, m, v read + written, grad read, shadow written
+
+    def quant(x):
+        return x.shape[0] * x.shape[1] * (es(x) + 1) + 4 * x.shape[0]
+
+    def transpose(x, out=None):
+        return 2 * x.numel() * es(x)
+
+    return {"layernorm_fwd": ("ln_fwd_kernel", ln_fwd), "layernorm_bwd": ("ln_bwd_kernel", ln_bwd), "ce_fwd": ("ce_fwd", ce_fwd),
+            "ce_bwd": ("ce_bwd_kernel", ce_bwd), "adamw": ("adamw_kernel", adamw), "quantize_rows_fp8": ("quantize_rows_fp8", quant),
+            "transpose": ("transpose", transpose)}
+
+
+def step_roofline(vit, model, opt, batch, pad, sync, ops, workload="cfg2", dtype_name="bf16", ms_per_step=None, hbm_bytes_out=None):
+    """HIP events (torch.cuda.Event records on the current stream = the stream the kernels are launched on) around every GEMM launch
+    and every HBM-bound op of ONE extra step that runs right behind the timed region.  That step runs the CLIP encode ON THE MAIN
+    STREAM (no cross-step overlap), so no bracket contains another stream's kernels: a bracket on the main stream beside a busy side
+    stream would charge the contention to the GEMM (round 2's cfg3 line reported 43.8 ms of GEMM inside a 30.6 ms step that way).
+      roofline      = the GEMM launches of the timed step's MAIN stream (mapper + LM forward / dgrad / wgrad): achieved = algorithmic
+                      FLOPs / sum of their durations.  They run one after another on that stream in the timed step too (beside the
+                      side stream they can only be slower), so gemm_ms_per_step <= ms_per_step by construction - checked here.
+      vit_tower_gemms = the CLIP tower's GEMMs (the side stream's work in the timed step), same measurement, reported beside it.
+      hbm_kernels   = LayerNorm fwd / bwd, CE fwd / bwd, AdamW, fp8 row quantiser, transposes: algorithmic bytes / duration / 8 TB/s.
+    With --dtype fp8 the dominant kernel is the fp8 GEMM (eavqa_gemm_fp8, priced against the 5 PFLOP/s dense fp8 peak); the bf16
+    launches of the main stream (the mapper) are reported beside it."""
+    real = {"gemm": ops.gemm, "gemm_fp8": ops.gemm_fp8}
+    models = _hbm_models()
+    for name in models:
+        real[name] = getattr(ops, name)
     recs = []
+    state = {"phase": "main"}
 
     def bracket(kind, flops, bytes_, call):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -458,7 +551,7 @@ def gemm_roofline(stepper, ops, workload="cfg2", dtype_name="bf16"):
         c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         c0.record()
         c1.record()
-        recs.append((kind, flops, bytes_, e0, e1, c0, c1))
+        recs.append((kind, state["phase"], flops, bytes_, e0, e1, c0, c1))
         return out
 
     def timed(a, b, *, a_kc=True, b_kc=True, **kw):
@@ -467,9 +560,10 @@ def gemm_roofline(stepper, ops, workload="cfg2", dtype_name="bf16"):
         o = kw.get("out")
         out_b = 4 if (kw.get("out_f32") or (o is not None and o.dtype == torch.float32)) else a.element_size()
         aux_b = a.element_size() if (kw.get("aux_in") is not None or kw.get("aux_out") is not None) else 0
-        res_b = 4 if kw.get("residual") is not None else 0
+        res = kw.get("residual")
+        res_b = res.element_size() if res is not None else 0
         algo = (M * K + N * K) * a.element_size() + M * N * (out_b + aux_b + res_b)
-        return bracket("bf16", 2.0 * M * N * K, algo, lambda: real(a, b, a_kc=a_kc, b_kc=b_kc, **kw))
+        return bracket("bf16", 2.0 * M * N * K, algo, lambda: real["gemm"](a, b, a_kc=a_kc, b_kc=b_kc, **kw))
 
     def timed8(aq, a_scale, bq, b_scale, **kw):
         M, K = aq.shape
@@ -479,46 +573,89 @@ def gemm_roofline(stepper, ops, workload="cfg2", dtype_name="bf16"):
         aux_b = 2 if (kw.get("aux_in") is not None or kw.get("aux_out") is not None) else 0
         res_b = 4 if kw.get("residual") is not None else 0
         algo = (M * K + N * K) + M * N * (out_b + aux_b + res_b)
-        return bracket("fp8", 2.0 * M * N * K, algo, lambda: real8(aq, a_scale, bq, b_scale, **kw))
+        return bracket("fp8", 2.0 * M * N * K, algo, lambda: real["gemm_fp8"](aq, a_scale, bq, b_scale, **kw))
+
+    def hbm_wrapper(name):
+        fn, model_bytes = real[name], models[name][1]
+        return lambda *a, **k: bracket("hbm:" + name, 0.0, float(model_bytes(*a, **k)), lambda: fn(*a, **k))
+
+    serial = Stepper(vit, model, opt, batch, pad, sync, overlap_vit=False)
+    enc = vit.encode_image
+
+    def tagged_encode(px):
+        state["phase"] = "vit"
+        try:
+            return enc(px)
+        finally:
+            state["phase"] = "main"
 
     ops.gemm, ops.gemm_fp8 = timed, timed8
+    for name in models:
+        setattr(ops, name, hbm_wrapper(name))
+    vit.encode_image = tagged_encode
     try:
-        # head start: keep the GPU busy for ~60 ms so that the whole instrumented step is enqueued before the GPU
+        # head start: keep the GPU busy for > 100 ms so that the whole instrumented step is enqueued before the GPU
         # reaches it - the event pairs then bracket pure device time, not host latency between record and launch
         blk_a = torch.randn(8192, 8192, device="cuda").to(torch.bfloat16)
         blk_c = torch.empty(8192, 8192, device="cuda", dtype=torch.bfloat16)
         for _ in range(150):                      # ~0.9 ms each
-            real(blk_a, blk_a, out=blk_c)
-        stepper.step()
-        stepper.flush()
+            real["gemm"](blk_a, blk_a, out=blk_c)
+        serial.step()
+        serial.flush()
         torch.cuda.synchronize()
     finally:
-        ops.gemm, ops.gemm_fp8 = real, real8
+        for name, fn in real.items():
+            setattr(ops, name, fn)
+        vit.encode_image = enc
+        del blk_a, blk_c
 
-    def summarise(kind, peak):
-        rs = [r for r in recs if r[0] == kind]
+    def seconds(rs):
+        raw = sum(r[4].elapsed_time(r[5]) for r in rs) * 1e-3
+        marker = sum(r[6].elapsed_time(r[7]) for r in rs) * 1e-3      # event-marker cost, per pair on average marker / n
+        return max(raw - marker, 0.5 * raw), marker
+
+    def summarise(kind, phase, peak):
+        rs = [r for r in recs if r[0] == kind and r[1] == phase]
         if not rs:
             return None
-        flops, algo, n = sum(r[1] for r in rs), sum(r[2] for r in rs), len(rs)
-        raw = sum(r[3].elapsed_time(r[4]) for r in rs) * 1e-3
-        marker = sum(r[5].elapsed_time(r[6]) for r in rs) * 1e-3      # event-marker cost, per pair on average marker / n
-        secs = max(raw - marker, 0.5 * raw)
+        flops, algo, n = sum(r[2] for r in rs), sum(r[3] for r in rs), len(rs)
+        secs, marker = seconds(rs)
         ach = flops / secs / 1e12
         return {"achieved": round(ach, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "launches_per_step": n,
                 "gflop_per_launch": round(flops / n / 1e9, 2), "avg_launch_us": round(secs / n * 1e6, 2),
                 "event_marker_us": round(marker / n * 1e6, 2), "gemm_ms_per_step": round(secs * 1e3, 3),
                 "algorithmic_bytes_per_launch": round(algo / n)}
 
+    hbm, hbm_dump = [], {}
+    for name, (pattern, _) in models.items():
+        rs = [r for r in recs if r[0] == "hbm:" + name]
+        if not rs:
+            continue
+        secs, _ = seconds(rs)
+        byts = sum(r[3] for r in rs)
+        gbps = byts / secs / 1e9
+        hbm.append({"op": "eavqa_" + name, "kernel": pattern, "launches_per_step": len(rs), "bytes_per_launch": round(byts / len(rs)),
+                    "avg_launch_us": round(secs / len(rs) * 1e6, 2), "achieved": round(gbps, 1), "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(gbps / 8000.0, 4)})
+        hbm_dump[name] = {"kernel_pattern": pattern, "launches_per_step": len(rs), "bytes_per_step": byts}
+    if hbm_bytes_out:
+        with open(hbm_bytes_out, "w") as f:
+            json.dump({"workload": workload, "dtype": dtype_name, "ops": hbm_dump}, f, indent=1)
+
     if dtype_name == "f32":
-        r = summarise("bf16", 157.3)
-        return {"bound": "mfma", "kernel": "eavqa_gemm: gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", **r, "traffic": None}
+        r = summarise("bf16", "main", 157.3)
+        return {"bound": "mfma", "kernel": "eavqa_gemm: gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", **r, "traffic": None, "traffic_source": None,
+                "vit_tower_gemms": summarise("bf16", "vit", 157.3), "hbm_kernels": hbm}
     main_kind = "fp8" if dtype_name == "fp8" else "bf16"
-    r = summarise(main_kind, 5000.0 if main_kind == "fp8" else 2500.0)
+    r = summarise(main_kind, "main", 5000.0 if main_kind == "fp8" else 2500.0)
     # HBM bytes per GEMM launch from committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     # runs, FETCH_SIZE x 2 on gfx950, KiB units; tools/pmc_traffic.py).  The file carries the digest of the GEMM sources it was
     # measured on: with other sources the figure is dropped, not reused.
     traffic, traffic_source = None, None
-    tfile = os.path.join(ROOT, "profiles", f"round2_gemm_traffic_{workload}_{dtype_name}.json")
+    for rnd in ("round3", "round2"):
+        tfile = os.path.join(ROOT, "profiles", f"{rnd}_gemm_traffic_{workload}_{dtype_name}.json")
+        if os.path.exists(tfile):
+            break
     if os.path.exists(tfile):
         with open(tfile) as f:
             t = json.load(f)
@@ -531,9 +668,14 @@ def gemm_roofline(stepper, ops, workload="cfg2", dtype_name="bf16"):
               if main_kind == "fp8" else
               "eavqa_gemm: gemm_bf16_k64s_kernel (loader / consumer specialised full-line tiles 128x80 / 256x128 / 256x160 / 128x128 / 128x256) "
               "+ gemm_bf16_big_kernel (256x256)")
-    out = {"bound": "mfma", "kernel": kernel, **r, "traffic": traffic, "traffic_source": traffic_source}
+    out = {"bound": "mfma", "kernel": kernel, "scope": "GEMM launches of the step's main stream (mapper + frozen LM); CLIP tower: vit_tower_gemms",
+           **r, "traffic": traffic, "traffic_source": traffic_source}
+    if ms_per_step is not None:
+        out["gemm_ms_within_step"] = bool(r["gemm_ms_per_step"] <= ms_per_step)
     if main_kind == "fp8":
-        out["bf16_gemms_same_step"] = summarise("bf16", 2500.0)
+        out["bf16_gemms_same_step"] = summarise("bf16", "main", 2500.0)
+    out["vit_tower_gemms"] = summarise("bf16", "vit", 2500.0)
+    out["hbm_kernels"] = hbm
     return out
 
 

@@ -682,16 +682,19 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
         const int blocks = B * ((H + 3) / 4);
         const int wph = blocks <= 256 ? 4 : (blocks <= 512 ? 2 : 1);
         const size_t v_image = (size_t)Sk * 4 * hd * 2;
-        const bool vlds = wph == 4 && v_image <= 128 * 1024;
-        const size_t lds = ((size_t)4 * Sk + 4 * wph * 128) * sizeof(float) + (vlds ? v_image : 0);
+        // the V image rides in LDS only when the WHOLE request (scores + per-wave scratch + image) fits the 150 KiB the kernel opts into;
+        // otherwise the register route (small head dims at long Sk: hd = 16, Sk ~ 1024 asked for 152 KiB and failed the launch)
+        const size_t lds_base = ((size_t)4 * Sk + 4 * wph * 128) * sizeof(float);
+        const bool vlds = wph == 4 && lds_base + v_image <= 150 * 1024;
+        const size_t lds = lds_base + (vlds ? v_image : 0);
         if (vlds) {
-            static bool configured[2] = {false, false};
+            static std::atomic<bool> configured[2];              // zero-initialised; concurrent first calls only repeat an idempotent call
             const int slot = hd <= 64 ? 0 : 1;
-            if (!configured[slot]) {
+            if (!configured[slot].load(std::memory_order_acquire)) {
                 const void* fn = hd <= 64 ? reinterpret_cast<const void*>(attn_decode_kernel<8, 4, 10, true>)
                                           : reinterpret_cast<const void*>(attn_decode_kernel<16, 4, 10, true>);
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return EAVQA_E_LAUNCH;
-                configured[slot] = true;
+                configured[slot].store(true, std::memory_order_release);
             }
         }
 #define EAVQA_DEC(LPK)                                                                                                       \

@@ -571,23 +571,23 @@ int launch(int which, const Params& p, hipStream_t s) {
         dim3 grid((p.Sq + TILE - 1) / TILE, p.B * p.H);
         hipLaunchKernelGGL((bwd_dq_kernel<KS, D16>), grid, dim3(256), 2 * row + TILE * 4, s, p);
     } else if (which == 3) {
-        static bool configured = false;
+        static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
         const size_t lds = 3 * row + TILE * (TILE * 2 + 16) + 2 * TILE * 4;
-        if (lds > 64 * 1024 && !configured) {
+        if (lds > 64 * 1024 && !configured.load(std::memory_order_acquire)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_fused_kernel<KS, D16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return EAVQA_E_LAUNCH;
-            configured = true;
+            configured.store(true, std::memory_order_release);
         }
         hipLaunchKernelGGL((bwd_fused_kernel<KS, D16>), dim3(1, p.B * p.H), dim3(256), lds, s, p);
     } else {
-        static bool configured = false;        // hd = 128: 2 x 17 KiB + 2 x 17 KiB + stats > 64 KiB
+        static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call        // hd = 128: 2 x 17 KiB + 2 x 17 KiB + stats > 64 KiB
         const size_t lds = 2 * row + 2 * TILE * 4;
-        if (lds > 64 * 1024 && !configured) {
+        if (lds > 64 * 1024 && !configured.load(std::memory_order_acquire)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(bwd_dkv_kernel<KS, D16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return EAVQA_E_LAUNCH;
-            configured = true;
+            configured.store(true, std::memory_order_release);
         }
         dim3 grid((p.Sk + TILE - 1) / TILE, p.B * p.H);
         hipLaunchKernelGGL((bwd_dkv_kernel<KS, D16>), grid, dim3(256), lds, s, p);

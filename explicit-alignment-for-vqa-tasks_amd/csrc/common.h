@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <atomic>
 #include "eavqa.h"
 
 typedef __bf16 bf16_t;

@@ -278,13 +278,13 @@ int gemm_splitk_impl(int dtype, int M, int N, int K, const void* A, int64_t lda,
                             {gemm_bf16_splitk_kernel<MFV, 2, 8, 8>, gemm_bf16_splitk_kernel<MFV, 2, 8, 16>}}}
     static const kernel_t kernels[3][2][2][2] = {EAVQA_SK_ROW(1), EAVQA_SK_ROW(2), EAVQA_SK_ROW(4)};      // [mf][NF][NW][U]
 #undef EAVQA_SK_ROW
-    static bool configured[3][2][2][2] = {};
+    static std::atomic<bool> configured[3][2][2][2];
     const int im = mf == 1 ? 0 : (mf == 2 ? 1 : 2), in = NF - 1, iw = NW == 8, iu = U == 16;
     const kernel_t kernel = kernels[im][in][iw][iu];
-    if (!configured[im][in][iw][iu]) {
+    if (!configured[im][in][iw][iu].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
             return EAVQA_E_LAUNCH;
-        configured[im][in][iw][iu] = true;
+        configured[im][in][iw][iu].store(true, std::memory_order_release);
     }
     const int cols = 16 * NF * NW;
     hipLaunchKernelGGL(kernel, dim3((N + cols - 1) / cols, ks), dim3(64 * NW), lds, reinterpret_cast<hipStream_t>(stream),

@@ -502,13 +502,13 @@ int launch_fast(const GemmParams& p, hipStream_t stream, const Knobs& kn) {
     static const fast_kernel_t kernels[8] = {gemm_bf16_fast_kernel<0, 4>, gemm_bf16_fast_kernel<1, 4>, gemm_bf16_fast_kernel<2, 4>,
                                              gemm_bf16_fast_kernel<3, 4>, gemm_bf16_fast_kernel<4, 4>,
                                              gemm_bf16_fast_kernel<0, 8>, gemm_bf16_fast_kernel<4, 8>, gemm_bf16_fast_kernel<5, 4>};
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
+    if (!configured.load(std::memory_order_acquire)) {
         for (int i = 0; i < 8; ++i)
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernels[i]), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     8 * FSTAGE) != hipSuccess)
                 return EAVQA_E_LAUNCH;
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     // deep ring (8 stages, one workgroup per CU): measured on MI355X to give no gain over 4 stages even for grids of one
     // tile per CU (the LDS-DMA rate of a CU is a throughput cap, not a bytes-in-flight limit) - kept as an experiment knob
@@ -729,12 +729,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
 template <int WM, int WN, int MF, int NF>
 int launch_shaped(const GemmParams& p, hipStream_t stream) {
     using G = TileGeo<WM, WN, MF, NF>;
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
+    if (!configured.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_shaped_kernel<WM, WN, MF, NF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
             return EAVQA_E_LAUNCH;
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
@@ -881,12 +881,12 @@ __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int g
 }
 
 int launch_big(const GemmParams& p, hipStream_t stream) {
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
+    if (!configured.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GLDS_BYTES) != hipSuccess)
             return EAVQA_E_LAUNCH;
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + GBM - 1) / GBM, tiles_n = (p.N + GBN - 1) / GBN;
     int best_gx = 8, best_cost = 1 << 30;
@@ -1137,15 +1137,17 @@ typedef void (*gemm_kernel_t)(GemmParams);
 int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
     // dynamic LDS above 64 KiB must be opted into once per kernel; remember which ones were
     // (idempotent, so a race between host threads only repeats the call)
-    static gemm_kernel_t configured[8] = {nullptr};
+    static std::atomic<gemm_kernel_t> configured[8];      // zero-initialised; a slot is claimed by compare-exchange
     bool done = false;
-    for (int i = 0; i < 8; ++i) done |= (configured[i] == kernel);
+    for (int i = 0; i < 8; ++i) done |= (configured[i].load(std::memory_order_acquire) == kernel);
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 CS_BYTES) != hipSuccess)
             return EAVQA_E_LAUNCH;
-        for (int i = 0; i < 8; ++i)
-            if (configured[i] == nullptr) { configured[i] = kernel; break; }
+        for (int i = 0; i < 8; ++i) {
+            gemm_kernel_t expected = nullptr;
+            if (configured[i].compare_exchange_strong(expected, kernel, std::memory_order_acq_rel) || expected == kernel) break;
+        }
     }
     const int nwg = p.tiles_m * p.tiles_n;
     hipLaunchKernelGGL(kernel, dim3(nwg), dim3(256), CS_BYTES, stream, p);

@@ -97,12 +97,12 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_fp8_k128s_kernel(Gem
 template <int WM, int WN, int MF, int NF, int NST, int LW, bool DB>
 int launch_fp8(const GemmParams& p, hipStream_t stream) {
     using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
+    if (!configured.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_k128s_kernel<WM, WN, MF, NF, NST, LW, DB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
             return EAVQA_E_LAUNCH;
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);

@@ -195,12 +195,12 @@ void gemm_bf16_k64_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n
 template <int WM, int WN, int MF, int NF, int NST, bool DB>
 int launch_k64(const GemmParams& p, hipStream_t stream) {
     using G = K64Geo<WM, WN, MF, NF, NST, DB>;
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
+    if (!configured.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64_kernel<WM, WN, MF, NF, NST, DB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
             return EAVQA_E_LAUNCH;
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
@@ -404,12 +404,12 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(Gem
 template <int WM, int WN, int MF, int NF, int NST, int LW>
 int launch_k64s(const GemmParams& p, hipStream_t stream) {
     using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
-    static bool configured = false;
-    if (!configured) {
+    static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
+    if (!configured.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
             return EAVQA_E_LAUNCH;
-        configured = true;
+        configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);

@@ -7,7 +7,6 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "eavqa.h"
-#include "decode_layer.h"
 
 namespace {
 inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }
@@ -43,10 +42,8 @@ extern "C" int64_t eavqa_lm_block_workspace_bytes(int dtype, int rows, int E, in
     return (int64_t)b;
 }
 
-// route (include/eavqa_test.h): 0 / 1 = one kernel per phase (the product route), 2 = the persistent one-kernel step of decode_layer.hip
-// or EAVQA_E_SHAPE.  The persistent kernel is correct (parity-tested) but SLOWER on MI355X - 6.6 against 2.93 ms per OPT-2.7B step: its
-// eight device-wide barriers per layer cost 7-10 us each in situ, as much as the kernel boundaries they replace, and a LayerNorm row
-// read through coherent 8-byte loads takes 17 us (profiles/round2_decode.md section 5) - so it is never chosen by shape.
+// route (include/eavqa_test.h): selects among decode-step structures for A / B measurements and parity tests; 0 = what the library ships.
+// (Round 2's persistent one-kernel step - route 2 then - measured 2.25x slower and now lives under tools/experiments/persistent_decode.)
 static int lm_block_forward_impl(int dtype, int n_layer, const eavqa_lm_layer_t* layers, int E, int H, int F, int act,
                                  float eps, int B, int Sq, int row0, int S_max, float* x, const int32_t* key_mask,
                                  int64_t ld_mask, void* workspace, int64_t workspace_bytes, void* stream, int route) {
@@ -77,11 +74,6 @@ static int lm_block_forward_impl(int dtype, int n_layer, const eavqa_lm_layer_t*
         const bool attn_from_partials = (hd % 8) == 0 && hd <= 128 && Sk <= 3584 && (E % 8) == 0;
         float* part = reinterpret_cast<float*>(w);
         float* part2 = reinterpret_cast<float*>(w + (d.part_bytes - align_up((size_t)d.ks_fc2 * rows * E * 4)));
-        if (route == 2 && attn_from_partials) {
-            rc = eavqa_detail_lm_decode_persistent(dtype, n_layer, layers, E, H, F, act, eps, B, row0, S_max, x, key_mask, ld_mask, a, ctx, x1, f, part,
-                                                   part2, d.ks_qkv, d.ks_o, d.ks_fc1, d.ks_fc2, stream);
-            if (rc != EAVQA_E_SHAPE || route == 2) return rc;
-        } else if (route == 2) return EAVQA_E_SHAPE;
         for (int l = 0; l < n_layer; ++l) {
             const eavqa_lm_layer_t& L = layers[l];
             // x = x1 + b_fc2 + sum(FFN-down partials of the previous layer); a = LN1(x)

@@ -47,14 +47,15 @@ class FlatParams:
         off = 0
         ordered = [ns for ns in named_shapes if len(ns[1]) <= 1] + [ns for ns in named_shapes if len(ns[1]) > 1]
         self.small_numel = 0
+        seen_matrix = False          # (a boolean, not `small_numel == 0`: a mapper without 1-D parameters has an EMPTY small region)
         for name, shape in ordered:
-            if len(shape) > 1 and self.small_numel == 0:
-                self.small_numel = off
+            if len(shape) > 1 and not seen_matrix:
+                self.small_numel, seen_matrix = off, True
             n = int(math.prod(shape))
             self.offsets[name] = (off, tuple(shape))
             off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
-        if self.small_numel == 0:
-            self.small_numel = off if all(len(sh) <= 1 for _, sh in ordered) else 0
+        if not seen_matrix:
+            self.small_numel = off   # 1-D parameters only
         big = off - self.small_numel
         off = self.small_numel + (big + self.SHARD_ALIGN - 1) // self.SHARD_ALIGN * self.SHARD_ALIGN
         self.numel = off
@@ -64,6 +65,13 @@ class FlatParams:
         self.shadow = self.master if compute_dtype == torch.float32 else torch.zeros(off, device=device, dtype=compute_dtype)
         self._shadow_version = -1
         self.grad_live = False   # False: the next backward overwrites ``grad`` instead of accumulating
+
+    def layout_tag(self) -> str:
+        """Digest of the flat layout (names, offsets, shapes, total length): optimiser moments are raw flat buffers, so a checkpoint
+        written under another layout must be refused rather than loaded misaligned."""
+        import hashlib
+        h = hashlib.sha256(repr((sorted(self.offsets.items()), self.numel, self.small_numel)).encode())
+        return h.hexdigest()[:16]
 
     def view(self, buf: Tensor, name: str) -> Tensor:
         off, shape = self.offsets[name]

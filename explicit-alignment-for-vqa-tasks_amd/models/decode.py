@@ -32,6 +32,16 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
     last decode step."""
     dev = lm.device
     S_max = S0 + max_length
+    if use_cache and getattr(lm, "weight_format", "native") != "native":
+        # the cached driver (eavqa_lm_block_forward) streams bf16 / fp32 weights; an fp8 LM takes the reference's own algorithm
+        # (full re-forward per token, src/models/clipcap.py:414-419) through the fp8 GEMMs - same ids, more work
+        global _warned_fp8_cache
+        if not _warned_fp8_cache:
+            import warnings
+            warnings.warn("greedy_decode: the KV-cached driver has no fp8-weight route; generating with use_cache=False "
+                          "(full re-forward per token, the reference's own loop)", RuntimeWarning, stacklevel=2)
+            _warned_fp8_cache = True
+        use_cache = False
     tokens = torch.zeros((B, max_length), dtype=torch.int64, device=dev)
     raw = torch.empty(B, dtype=torch.int32, device=dev)
     unfinished = torch.ones(B, dtype=torch.int32, device=dev)
@@ -59,6 +69,9 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
     if output_scores:
         return ids, logp[:produced].t().contiguous().cpu()
     return ids
+
+
+_warned_fp8_cache = False
 
 
 def _mark(marks: Optional[list], name: str) -> None:

@@ -35,7 +35,7 @@ class KernelSelect:
     state lives HERE, in the test-facing Python layer - libeavqa_hip.so itself holds no mutable state."""
     gemm = 0
     attention = 0
-    decode_route = 0      # eavqa_lm_block_forward_ex: 0 / 1 one kernel per phase (product route), 2 the persistent one-kernel step
+    decode_route = 0      # eavqa_lm_block_forward_ex: 0 = the shipped decode-step structure, other values = A / B alternatives
 
 
 def _p(t: Optional[Tensor]) -> Optional[int]:

@@ -212,6 +212,11 @@ class ClipCapExecutor:
 
     # ------------------------------------------------------------------ checkpoints (mapper only + LM identity)
     def state_dict(self):
+        # under the sharded optimiser (bf16 operand mode) every rank updates only ITS shards of the fp32 master copy: gather the
+        # whole master first, or the checkpoint would hold stale rows for the shards this rank does not own
+        gather = getattr(self.optimizer, "gather_master", None)
+        if gather is not None:
+            gather()
         sd = {"model.clip_project." + k: v.detach().cpu() for k, v in self.model.clip_project.state_dict().items()}
         return {"state_dict": sd, "global_step": self.global_step,
                 "optimizer": None if self.optimizer is None else {k: (v.cpu() if torch.is_tensor(v) else v)

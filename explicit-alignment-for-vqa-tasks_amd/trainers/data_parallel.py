@@ -66,6 +66,7 @@ class GradSync:
         self.on_gpu = flat_grad.is_cuda
         self.stream = torch.cuda.Stream() if (self.on_gpu and self.exchange) else None
         self._pending = None
+        self._ev = None                                  # (start, end) HIP events of the last exchange, on the exchange stream
 
     @property
     def grad_scale(self) -> float:
@@ -79,15 +80,36 @@ class GradSync:
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
-                self._pending = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
+                work = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if dist.get_backend(self.group) == "nccl":
+                    # RCCL runs the collective on c10d's internal stream; wait() only makes THIS side stream wait for it (the
+                    # host does not block), so the end marker brackets the collective's device time
+                    work.wait()
+                    e1.record(self.stream)
+                    self._ev = (e0, e1)
+                    work = None
+                self._pending = work
+                self._started = True
         else:
             self._pending = dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._started = True
 
     def finish(self) -> None:
         """Make the current stream wait for the exchange (call right before the optimiser step)."""
-        if self._pending is None:
+        if not getattr(self, "_started", False):
             return
-        self._pending.wait()
+        if self._pending is not None:
+            self._pending.wait()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._pending = None
+        self._started = False
+
+    def last_exchange_ms(self):
+        """Device milliseconds of the last all-reduce (HIP events on the exchange stream; waits for the end event), or None."""
+        if self._ev is None:
+            return None
+        self._ev[1].synchronize()
+        return round(self._ev[0].elapsed_time(self._ev[1]), 3)

@@ -33,13 +33,24 @@ class FusedAdamW:
         self.flat.grad_live = False
 
     def state_dict(self):
-        return dict(step=self.step_count, m=self.m, v=self.v, param_groups=self.param_groups)
+        return dict(step=self.step_count, m=self.m, v=self.v, param_groups=self.param_groups, layout=self.flat.layout_tag())
 
     def load_state_dict(self, sd) -> None:
+        _check_layout(self.flat, sd, self.m)
         self.step_count = int(sd["step"])
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.param_groups = sd["param_groups"]
+
+
+def _check_layout(flat, sd, m) -> None:
+    """The moments are raw flat buffers: refuse a state written under another parameter layout (FlatParams orders 1-D parameters
+    first and pads the matrix region; a state from an older layout would load misaligned where the sizes happen to match)."""
+    tag = sd.get("layout")
+    if tag is not None and tag != flat.layout_tag():
+        raise ValueError("optimiser state was written under another flat parameter layout (layout tag mismatch)")
+    if tag is None and tuple(sd["m"].shape) != tuple(m.shape):
+        raise ValueError(f"optimiser state without a layout tag and of another size ({tuple(sd['m'].shape)} vs {tuple(m.shape)})")
 
 
 class ConstantScheduleWithWarmup:
@@ -111,10 +122,13 @@ class ShardedAdamW:
         all-gather of the compute-dtype shards                          -> every rank has the whole updated operand copy
 
     Bytes per rank and step: (world-1)/world x (4 + 2) B/parameter instead of the all-reduce's 2 x (world-1)/world x 4, optimiser
-    traffic and moment memory 1/world; xGMI is point-to-point, so both collectives are per-link bound and the
-    bucket pipeline keeps one collective in flight while the previous bucket's AdamW runs.  The 1-D parameters (biases, LayerNorm
-    affine: ``FlatParams.small_numel`` leading elements, read in fp32 by the kernels) stay replicated: one small all-reduce and
-    a redundant update on every rank.
+    traffic and moment memory 1/world; xGMI is point-to-point, so both collectives are per-link bound.  All
+    collectives are issued asynchronously (``_run``): the reduce-scatters queue up front on c10d's collective stream, bucket b's
+    AdamW runs on the side stream while bucket b+1's reduce-scatter is on the wire, each all-gather is queued as soon as its shard
+    is updated.  The 1-D parameters (biases, LayerNorm affine: ``FlatParams.small_numel`` leading elements, read in fp32 by the
+    kernels) stay replicated: one small asynchronous all-reduce issued first and a redundant update on every rank (nothing
+    blocks on it).  UNMEASURED on more than one GPU (no multi-GPU box has run this tree): correct under gloo world size 2 and
+    RCCL in a group of one.
 
     Layout of the matrix region [small, numel): ``n_buckets`` contiguous buckets of ``world x piece`` elements; rank r owns
     [r x piece, (r+1) x piece) of every bucket, so each collective works on one contiguous range (in place for the gather).
@@ -147,6 +161,8 @@ class ShardedAdamW:
         self.multi = self.world > 1 or (collectives_in_group_of_one and dist.is_initialized())
         self.stream = torch.cuda.Stream() if (flat.master.is_cuda and self.multi) else None
         self._busy = False
+        self._master_stale = False
+        self._ev = None                                  # (start, end) HIP events of the last exchange + update, on the side stream
 
     @property
     def grad_scale(self) -> float:
@@ -164,22 +180,39 @@ class ShardedAdamW:
                   grad_scale=grad_scale)
         lowp = fl.shadow is not fl.master
         multi = self.multi
-        if self.small:
-            if multi:
-                dist.all_reduce(fl.grad[:self.small], op=dist.ReduceOp.SUM, group=self.group)
-            self.adamw(fl.master[:self.small], fl.grad[:self.small], self.m_small, self.v_small, shadow=fl.shadow[:self.small] if lowp else None, **kw)
+        # Every collective is ASYNC: c10d runs them in issue order on its own stream, so all reduce-scatters (and, first, the small
+        # all-reduce of the replicated 1-D parameters) are queued up front; bucket b's AdamW waits only for ITS reduce-scatter and
+        # runs on this stream while bucket b+1's reduce-scatter is on the wire; its all-gather is queued as soon as the shard is
+        # updated.  Nothing blocks the host (RCCL work.wait() is a stream wait); gloo (CPU tests) blocks in wait(), same order.
+        w_small = None
+        if self.small and multi:
+            w_small = dist.all_reduce(fl.grad[:self.small], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        rs = []
+        if multi:
+            for b in range(self.n_buckets):
+                lo, hi, _ = self._bucket(b)
+                rs.append(dist.reduce_scatter_tensor(self.gshard[b * self.piece:(b + 1) * self.piece], fl.grad[lo:hi], op=dist.ReduceOp.SUM,
+                                                     group=self.group, async_op=True))
+        ag = []
         for b in range(self.n_buckets):
             lo, hi, mine = self._bucket(b)
-            gs = self.gshard[b * self.piece:(b + 1) * self.piece]
             if multi:
-                dist.reduce_scatter_tensor(gs, fl.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                rs[b].wait()
+                gs = self.gshard[b * self.piece:(b + 1) * self.piece]
             else:
                 gs = fl.grad[lo:hi]
             self.adamw(fl.master[mine:mine + self.piece], gs, self.m[b * self.piece:(b + 1) * self.piece], self.v[b * self.piece:(b + 1) * self.piece],
                        shadow=fl.shadow[mine:mine + self.piece] if lowp else None, **kw)
             if multi:
                 # in place: rank r's input is its own slice of the output
-                dist.all_gather_into_tensor(fl.shadow[lo:hi], fl.shadow[mine:mine + self.piece], group=self.group)
+                ag.append(dist.all_gather_into_tensor(fl.shadow[lo:hi], fl.shadow[mine:mine + self.piece], group=self.group, async_op=True))
+        if self.small:
+            if w_small is not None:
+                w_small.wait()
+            self.adamw(fl.master[:self.small], fl.grad[:self.small], self.m_small, self.v_small, shadow=fl.shadow[:self.small] if lowp else None, **kw)
+        for w in ag:
+            w.wait()
+        self._master_stale = multi and lowp          # non-owned master shards are not updated in bf16-operand mode: gather_master()
         fl.mark_shadow_fresh()
 
     def start(self, grad_scale: float = None) -> None:
@@ -188,7 +221,11 @@ class ShardedAdamW:
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self.stream)
                 self._run(scale)
+                e1.record(self.stream)
+                self._ev = (e0, e1)
         else:
             self._run(scale)
         self._busy = True
@@ -198,6 +235,13 @@ class ShardedAdamW:
         if self._busy and self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
         self._busy = False
+
+    def last_exchange_ms(self):
+        """Device milliseconds of the last exchange + sharded update (HIP events on the side stream), or None."""
+        if self._ev is None:
+            return None
+        self._ev[1].synchronize()
+        return round(self._ev[0].elapsed_time(self._ev[1]), 3)
 
     def step(self, grad_scale: float = None) -> None:
         """Optimiser-style entry: exchange + update + wait."""
@@ -215,15 +259,17 @@ class ShardedAdamW:
             for b in range(self.n_buckets):
                 lo, hi, mine = self._bucket(b)
                 dist.all_gather_into_tensor(fl.master[lo:hi], fl.master[mine:mine + self.piece], group=self.group)
+        self._master_stale = False
         return fl.master
 
     def state_dict(self):
         return dict(step=self.step_count, m=self.m, v=self.v, m_small=self.m_small, v_small=self.v_small, param_groups=self.param_groups,
-                    world=self.world, rank=self.rank, n_buckets=self.n_buckets)
+                    world=self.world, rank=self.rank, n_buckets=self.n_buckets, layout=self.flat.layout_tag())
 
     def load_state_dict(self, sd) -> None:
         if (sd["world"], sd["rank"], sd["n_buckets"]) != (self.world, self.rank, self.n_buckets):
             raise ValueError("sharded optimiser state belongs to another world size / rank / bucket count")
+        _check_layout(self.flat, sd, self.m)
         self.step_count = int(sd["step"])
         for name in ("m", "v", "m_small", "v_small"):
             getattr(self, name).copy_(sd[name])

@@ -51,8 +51,8 @@ int eavqa_attention_bwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
 int eavqa_gemm_splitk_ex(int dtype, int M, int N, int K, const void* A, int64_t lda, const void* B, int64_t ldb,
                          float* partials, int ks, void* stream, int unroll);
 
-/* eavqa_lm_block_forward with the decode route as an argument: 0 / 1 = one kernel per phase (what the library does), 2 = the persistent
- * one-kernel step (csrc/decode_layer.hip: measured slower, kept as a tested experiment) or EAVQA_E_SHAPE when the shape is not covered. */
+/* eavqa_lm_block_forward with the decode-step structure as an argument, for A / B measurements and parity tests of alternative
+ * structures against the shipped one: 0 = what the library does; values the build does not know behave like 0. */
 int eavqa_lm_block_forward_ex(int dtype, int n_layer, const eavqa_lm_layer_t* layers, int E, int H, int F, int act, float eps,
                               int B, int Sq, int row0, int S_max, float* x, const int32_t* key_mask, int64_t ld_mask,
                               void* workspace, int64_t workspace_bytes, void* stream, int route);

@@ -299,13 +299,15 @@ def main():
          **_np(clip.state_dict(), "w."))
 
 
-def formatter_golden():
-    """Strings produced by the reference ``InContextExampleFormatter`` (src/utils/in_context_examples.py:114-218) for every
-    format type, 0 and 2 in-context examples, joined and per-example modes.  The module imports ``clip`` (absent, un-pinned)
-    and ``easydict`` (absent) at the top: both are stubbed in memory, neither is used by the formatter."""
-    import json
-    clip = types.ModuleType("clip")
-    sys.modules.setdefault("clip", clip)
+def _install_import_stubs():
+    """In-memory stand-ins for the two third-party modules the reference's data / formatter modules import at the top and this
+    container lacks: ``clip`` (unused by the code under test) and ``easydict``.  ONE recursive ``EasyDict`` serves both the formatter
+    and the ModuleParser step (round 2 registered a simpler one first, and a full run of this script then handed it to the
+    ModuleParser step through ``sys.modules.setdefault``, which needs the recursive behaviour).  Returns the EasyDict class."""
+    if "clip" not in sys.modules:
+        sys.modules["clip"] = types.ModuleType("clip")
+    if "easydict" in sys.modules and hasattr(sys.modules["easydict"], "EasyDict"):
+        return sys.modules["easydict"].EasyDict
     ed = types.ModuleType("easydict")
 
     class EasyDict(dict):
@@ -313,9 +315,26 @@ def formatter_golden():
             super().__init__()
             for k, v in dict(d or {}, **kw).items():
                 self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            elif isinstance(v, list):
+                v = [EasyDict(x) if isinstance(x, dict) and not isinstance(x, EasyDict) else x for x in v]
+            super().__setitem__(k, v)
         __getattr__ = dict.__getitem__
+        __setattr__ = __setitem__
     ed.EasyDict = EasyDict
-    sys.modules.setdefault("easydict", ed)
+    sys.modules["easydict"] = ed
+    return EasyDict
+
+
+def formatter_golden():
+    """Strings produced by the reference ``InContextExampleFormatter`` (src/utils/in_context_examples.py:114-218) for every
+    format type, 0 and 2 in-context examples, joined and per-example modes.  The module imports ``clip`` (absent, un-pinned)
+    and ``easydict`` (absent) at the top: both are stubbed in memory, neither is used by the formatter."""
+    import json
+    EasyDict = _install_import_stubs()
     sys.path.insert(0, "/root/reference/src/utils")
     import in_context_examples as ice
     # the inputs of src/utils/in_context_examples_test.py:9-51 (test DATA)
@@ -505,27 +524,7 @@ def module_parser_golden():
     (``configs/vqa2/few_shot_vqa_hotpotqa.jsonnet:46-56``: QInput + EmbeddingInput), with and without permutations."""
     import importlib.util
     import json
-    clip = types.ModuleType("clip")
-    sys.modules.setdefault("clip", clip)
-    ed = types.ModuleType("easydict")
-
-    class EasyDict(dict):
-        def __init__(self, d=None, **kw):
-            super().__init__()
-            for k, v in dict(d or {}, **kw).items():
-                self[k] = v
-
-        def __setitem__(self, k, v):
-            if isinstance(v, dict) and not isinstance(v, EasyDict):
-                v = EasyDict(v)
-            elif isinstance(v, list):
-                v = [EasyDict(x) if isinstance(x, dict) and not isinstance(x, EasyDict) else x for x in v]
-            super().__setitem__(k, v)
-        __getattr__ = dict.__getitem__
-        __setattr__ = __setitem__
-    ed.EasyDict = EasyDict
-    sys.modules.setdefault("easydict", ed)
-    EasyDict = sys.modules["easydict"].EasyDict
+    EasyDict = _install_import_stubs()
     sys.path.insert(0, "/root/reference/src")
     spec = importlib.util.spec_from_file_location("ref_module_parser", "/root/reference/src/data_loader_manager/module_parser.py")
     mp = importlib.util.module_from_spec(spec)

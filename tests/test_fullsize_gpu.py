@@ -22,6 +22,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import oracle
+from _metrics import grad_stats
 
 DEV = "cuda"
 
@@ -119,8 +120,10 @@ def test_training_step_real_size_matches_oracle(name, vit_name, lm_name, B):
         e = dict(emb=(r["emb"] - emb).abs().max().item(), logits=(r["logits"] - logits)[attended].abs().max().item(),
                  loss=abs(r["loss"] - loss.item()),
                  grad=max((r["grads"][k] - g).abs().max().item() / max(g.abs().max().item(), 1e-12) for k, g in grads.items()))
+        e["cos"], e["ratio"], _ = grad_stats(r["grads"], grads)
         print(f"[{name} {tag}] max|d emb| {e['emb']:.2e}  max|d logits| {e['logits']:.2e}  |d loss| {e['loss']:.2e}  "
-              f"max rel d grad {e['grad']:.2e}  (|logits| max {logits.abs().max().item():.2f}, loss {loss.item():.4f})")
+              f"max rel d grad {e['grad']:.2e}  gradient cosine {e['cos']:.5f}  norm ratio {e['ratio']:.4f}  "
+              f"(|logits| max {logits.abs().max().item():.2f}, loss {loss.item():.4f})")
         return e
 
     e = report("fp32", f32)
@@ -149,6 +152,8 @@ def test_training_step_real_size_matches_oracle(name, vit_name, lm_name, B):
         tols["grad"] = 0.25      # measured 0.135 on cfg3: bf16 pre-activations (2^-9 spacing) flip far more ReLU derivatives than fp32 ones do
     for k, tol in tols.items():
         assert e[k] <= tol, (k, e)
+    # direction and length of the whole mapper gradient (max-rel of the largest entry alone is a poor statistic: VERDICT round 2)
+    assert e["cos"] >= (0.99 if cfg.act == "relu" else 0.9995) and abs(e["ratio"] - 1.0) <= 0.03, e
     # the padded (reference-layout) forward must agree with the packed one at this depth too
     bf_pad = _hip_train(cfg, sd, vit_name, vsd, torch.bfloat16, b, L, mapper_sd=f32["mapper"], pack=False)
     assert abs(bf_pad["loss"] - bf["loss"]) <= 5e-3
@@ -306,10 +311,15 @@ def test_cfg5_fp8_training_step_real_size():
                                           ids, prefix, mask, labels)
     loss.backward()
     e_log = (got_logits - logits.detach()).abs().max().item()
-    e_grad = max((got_grads[k] - p.grad).abs().max().item() / max(p.grad.abs().max().item(), 1e-12) for k, p in mp.items())
+    cos, ratio, e_grad = grad_stats(got_grads, {k: p.grad for k, p in mp.items()})
     print(f"[cfg5 fp8] |d loss| {abs(got_loss - loss.item()):.3e} (loss {loss.item():.4f})  max|d logits| {e_log:.3e} (|logits| max "
-          f"{logits.abs().max().item():.2f})  max rel d grad {e_grad:.3e}   [GPU leg {t1 - t0:.0f} s, CPU leg {time.time() - t1:.0f} s]")
+          f"{logits.abs().max().item():.2f})  mapper gradient cosine {cos:.4f}  norm ratio {ratio:.4f}  max rel {e_grad:.3e}   "
+          f"[GPU leg {t1 - t0:.0f} s, CPU leg {time.time() - t1:.0f} s]")
     # measured on MI355X: |d loss| 2.0e-2, max |d logits| 0.61 (|logits| max ~ 12), max rel d grad 0.45 - e4m3
     # activations (3 mantissa bits) through 32 ReLU layers; the kernels themselves are pinned at operator level (tests/test_fp8_gpu.py).
     # Bounds = 2x the measured values.
-    assert abs(got_loss - loss.item()) <= 5e-2 and e_log <= 1.2 and e_grad <= 0.9
+    assert abs(got_loss - loss.item()) <= 5e-2 and e_log <= 1.2
+    # direction and length of the WHOLE mapper gradient: what a wrong dgrad cannot pass (zero: ratio 0; sign error: cosine -1; wrong
+    # scale / transposed weight: cosine ~ 0).  The max-rel of the largest entry (0.45 measured) is printed, not judged: e4m3 forward
+    # activations flip ReLU derivatives through 32 layers (tests/test_fp8_numerics_model.py: the gradient operand's format is not the cause)
+    assert cos >= 0.85 and 0.85 <= ratio <= 1.18, (cos, ratio)
