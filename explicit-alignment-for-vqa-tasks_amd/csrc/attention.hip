@@ -720,6 +720,8 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
         m.B = B; m.H = H; m.Sq = Sq; m.Sk = Sk; m.hd = hd; m.causal = causal; m.stat_ld = Sq;
         m.bsq = p.bsq; m.bsk = p.bsk; m.scale = scale;
         if (wide) return eavqa_attn_mfma::run_wide(0, m, s);
+        // K / V resident in LDS (the CLIP tower: one workgroup per (image, head)); path bit 2 keeps the streamed-tile kernel (A / B, tests)
+        if (!(path & 4) && (Sk > 64 || (path & 8)) && eavqa_attn_mfma::resident_supported(m)) return eavqa_attn_mfma::run_resident(m, s);
         return eavqa_attn_mfma::run(0, m, s);
     }
     return dtype == EAVQA_F32 ? dispatch<float>(K_FWD, p, s) : dispatch<bf16_t>(K_FWD, p, s);

@@ -37,6 +37,9 @@ struct Params {
 
 constexpr int TILE = 64;
 
+// s_waitcnt immediate that waits for vmcnt <= n only (lgkmcnt / expcnt untouched)
+__device__ __host__ constexpr int vm_only_attn(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0F70; }
+
 template <int KS> struct Geo {
     static constexpr int HP = KS * 32;              // head dim padded to the MFMA k step
     static constexpr int PR = HP * 2 + 16;          // byte pitch of a row-major [item][d] image (16 B pad: bank spread)
@@ -286,6 +289,176 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
         for (int dm = 0; dm < D16; ++dm) store4(O, p.ldo, qi, head_off, 16 * dm + 4 * g, p.hd, acc[dm], inv);
         if (p.lse && g == 0) p.lse[((int64_t)b * p.H + h) * p.stat_ld + qi] = m + __logf(l);
     }
+}
+
+// ------------------------------------------------------------------------------------ forward, K / V resident in LDS (hd = 64)
+// The CLIP tower's attention (ViT-L/14: 257 tokens x 16 heads x 160 images per few-shot batch, no mask) was 3 x HBM-bound in the
+// streamed kernel above: each (image, head) problem was cut into three workgroups of 96 queries that each staged all of K and V
+// again (on three different XCDs: consecutive blocks land on different L2s), through registers, with two barriers per 64-key
+// tile.  Here ONE workgroup owns the whole (image, head) problem:
+//   * all of K and V (N x 64 bf16 each, 36 KiB at N = 257, 74 KiB at N = 577) arrive ONCE by LDS-DMA (1-KiB pieces of eight
+//     128-byte rows, no registers) into two row-major images that stay for the lifetime of the workgroup: one barrier in all;
+//   * image rows are 128 bytes; 16-byte chunk c of row r sits at slot c ^ (r & 6) (applied on the DMA's per-lane SOURCE address,
+//     the same involution on every read).  That one swizzle makes BOTH kinds of read conflict-free: the ds_read_b128 row reads of
+//     K (16-lane groups hold rows {0-3, 12-15} at chunk a and rows {4-11} at chunk a ^ 1: r & 6 sends the 8 rows of either
+//     parity to 8 different slots) and the ds_read_b64_tr_b16 transposed reads of V (a 32-lane half reads 8 consecutive rows x 2
+//     adjacent chunks: bit 0 of the chunk index is untouched, so the pair stays adjacent, and r & 6 spreads the rows);
+//   * a wave owns 32 queries (two B fragments), so every K / V^T fragment read from LDS feeds two MFMAs: half the LDS traffic per
+//     FLOP of the 16-query waves above (whose 4 LDS cycles per 16-cycle MFMA on four SIMDs are exactly the LDS's whole rate);
+//   * waves walk the query blocks independently (no barrier after the staging one).
+// Rows beyond N in the images are copies of row N - 1 (clamped DMA source: finite values); their scores are masked to -inf.
+__device__ __forceinline__ int res_off(int row, int chunk) { return row * 128 + ((chunk ^ (row & 6)) << 4); }
+
+__global__ __launch_bounds__(1024, 4) void fwd_resident64_kernel(Params p, int npad, int nqb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vs = smem + npad * 128;
+    const int bh = blockIdx.x, b = bh / p.H, h = bh - b * p.H;
+    const int lane = threadIdx.x & 63, x = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nw = blockDim.x >> 6;
+    const int N = p.Sk, head_off = h * 64;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + (int64_t)b * p.bsq * p.ldq;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + (int64_t)b * p.bsk * p.ldk;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + (int64_t)b * p.bsk * p.ldv;
+    {
+        // piece i < npieces: K rows 8 i .. 8 i + 7; piece npieces + i: the same rows of V.  Lane l of a piece: row 8 i + (l >> 3), slot l & 7.
+        const int npieces = npad >> 3, r8 = lane >> 3, slot = lane & 7;
+        for (int i = wave; i < 2 * npieces; i += nw) {
+            const bool isv = i >= npieces;
+            const int piece = isv ? i - npieces : i;
+            const int row = piece * 8 + r8;
+            const bf16_t* src = (isv ? V + (int64_t)min(row, N - 1) * p.ldv : K + (int64_t)min(row, N - 1) * p.ldk) + head_off + ((slot ^ (row & 6)) << 3);
+            char* dst = (isv ? Vs : Ks) + piece * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(vm_only_attn(0));
+    __syncthreads();
+
+    const float c2 = p.scale * 1.4426950408889634f;
+    const int tq = x >> 2, pp = x & 3;
+    for (int qb = wave; qb < nqb; qb += nw) {
+        const int qa = qb * 32 + x, qc = qa + 16;
+        bf16x8 qfa[2], qfb[2];
+        load_bfrag<2>(qfa, Q, p.ldq, qa, qa < N, 64, head_off, g);
+        load_bfrag<2>(qfb, Q, p.ldq, qc, qc < N, 64, head_off, g);
+        f32x4 oa[4], ob[4];
+#pragma unroll
+        for (int dm = 0; dm < 4; ++dm) { oa[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; ob[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        float ma = -FLT_MAX, mb = -FLT_MAX, la = 0.f, lb = 0.f;          // running max in SCALED units (score * scale)
+        for (int k0 = 0; k0 < N; k0 += TILE) {
+            const int nf = min(4, (N - k0 + 15) >> 4);                    // 16-key fragments of this tile that hold a key
+            f32x4 sa[4], sb[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                sa[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                sb[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (f < nf) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + res_off(k0 + 16 * f + x, 4 * s + g));
+                        sa[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qfa[s], sa[f], 0, 0, 0);
+                        sb[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qfb[s], sb[f], 0, 0, 0);
+                    }
+                }
+                if (f == 1) __builtin_amdgcn_sched_barrier(0);            // at most four K fragments in flight (registers: 128 per lane)
+            }
+            if (k0 + TILE > N) {                                          // last tile: keys that do not exist
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (k0 + 16 * f + 4 * g + r >= N) { sa[f][r] = -INFINITY; sb[f][r] = -INFINITY; }
+            }
+            float ta = -FLT_MAX, tb = -FLT_MAX;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ta = fmaxf(ta, sa[f][r]); tb = fmaxf(tb, sb[f][r]); }
+            // exp((s - m) scale) = exp2(s c2 - m'), m' = the running maximum in log2 units (scale > 0: max commutes with it)
+            const float na = fmaxf(ma, group4_max(ta) * c2), nb = fmaxf(mb, group4_max(tb) * c2);
+            const float ca = __builtin_amdgcn_exp2f(ma - na), cb = __builtin_amdgcn_exp2f(mb - nb);
+            la *= ca; lb *= cb;
+#pragma unroll
+            for (int dm = 0; dm < 4; ++dm) {
+                oa[dm][0] *= ca; oa[dm][1] *= ca; oa[dm][2] *= ca; oa[dm][3] *= ca;
+                ob[dm][0] *= cb; ob[dm][1] *= cb; ob[dm][2] *= cb; ob[dm][3] *= cb;
+            }
+            ma = na; mb = nb;
+            // per half of the tile (32 keys): P^T = exp2(...) as bf16 B fragments (k order of the accumulator-as-B trick: registers 0-3 of two
+            // adjacent 16-key tiles), then O^T += V^T . P^T with the A operand (rows = d, k = keys in that permuted order) from two
+            // transposing reads of the row-major V image
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if (s2 == 1 && nf <= 2) break;                            // keys 32 .. 63 of the tile do not exist
+                __builtin_amdgcn_sched_barrier(0);                        // keeps the second half's reads out of the first half (registers)
+                bf16x8 pa8, pb8;
+#pragma unroll
+                for (int ff = 0; ff < 2; ++ff)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pa = __builtin_amdgcn_exp2f(fmaf(sa[2 * s2 + ff][r], c2, -na)), pb = __builtin_amdgcn_exp2f(fmaf(sb[2 * s2 + ff][r], c2, -nb));
+                        la += pa; lb += pb;
+                        pa8[4 * ff + r] = (bf16_t)pa;
+                        pb8[4 * ff + r] = (bf16_t)pb;
+                    }
+                const int row_lo = k0 + 32 * s2 + 4 * g + tq;            // (row_lo + 16) & 6 == row_lo & 6
+                const char* base = Vs + row_lo * 128 + 8 * (pp & 1);
+                const int sw = row_lo & 6, half = pp >> 1;
+#pragma unroll
+                for (int dm = 0; dm < 4; ++dm) {
+                    const int off = ((2 * dm + half) ^ sw) << 4;
+                    const bf16x4 lo = lds_tr4(base + off);
+                    const bf16x4 hi = lds_tr4(base + 16 * 128 + off);
+                    bf16x8 a;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
+                    oa[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pa8, oa[dm], 0, 0, 0);
+                    ob[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pb8, ob[dm], 0, 0, 0);
+                }
+            }
+        }
+        const float lta = group4_sum(la), ltb = group4_sum(lb);
+        bf16_t* O = reinterpret_cast<bf16_t*>(p.out) + (int64_t)b * p.bsq * p.ldo;
+        if (qa < N) {
+            const float inv = 1.f / lta;
+#pragma unroll
+            for (int dm = 0; dm < 4; ++dm) store4(O, p.ldo, qa, head_off, 16 * dm + 4 * g, 64, oa[dm], inv);
+            if (p.lse && g == 0) p.lse[((int64_t)b * p.H + h) * p.stat_ld + qa] = ma * 0.6931471805599453f + __logf(lta);
+        }
+        if (qc < N) {
+            const float inv = 1.f / ltb;
+#pragma unroll
+            for (int dm = 0; dm < 4; ++dm) store4(O, p.ldo, qc, head_off, 16 * dm + 4 * g, 64, ob[dm], inv);
+            if (p.lse && g == 0) p.lse[((int64_t)b * p.H + h) * p.stat_ld + qc] = mb * 0.6931471805599453f + __logf(ltb);
+        }
+    }
+}
+
+// the resident kernel's domain: self-attention (Sq == Sk) over at most 592 positions with hd = 64, no mask, no packing
+bool resident_supported(const Params& p) {
+    return p.hd == 64 && !p.causal && !p.key_mask && !p.cu && p.Sq == p.Sk && p.Sk <= 592 && p.scale > 0.f &&
+           !(p.ldq % 8 || p.ldk % 8 || p.ldv % 8 || p.ldo % 4) && eavqa_aligned16(p.q) && eavqa_aligned16(p.k) && eavqa_aligned16(p.v);
+}
+
+int run_resident(const Params& p, hipStream_t s) {
+    const int N = p.Sk, npad = (N + 31) / 32 * 32, nqb = (N + 31) / 32;
+    const size_t lds = (size_t)2 * npad * 128;
+    // waves per workgroup: 128 VGPRs allow 16 waves per CU; images of <= 80 KiB let two workgroups share a CU (one stages while the
+    // other multiplies), so those take at most 8 waves each; wave w walks query blocks w, w + nw, ...
+    const int max_nw = lds <= 80 * 1024 ? 8 : 16;
+    const int rounds = (nqb + max_nw - 1) / max_nw;
+    const int nw = rounds == 1 ? nqb : ((nqb - 1) % max_nw == 0 ? max_nw : (nqb + rounds - 1) / rounds);   // a lone last block rides on wave 0
+    static std::atomic<bool> configured{false};
+    if (lds > 64 * 1024 && !configured.load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(fwd_resident64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024) != hipSuccess)
+            return EAVQA_E_LAUNCH;
+        configured.store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(fwd_resident64_kernel, dim3(p.B * p.H), dim3(64 * nw), lds, s, p, npad, nqb);
+    if (hipGetLastError() != hipSuccess) return EAVQA_E_LAUNCH;
+    return EAVQA_OK;
 }
 
 // ------------------------------------------------------------------------------------ backward: dQ (+ delta)

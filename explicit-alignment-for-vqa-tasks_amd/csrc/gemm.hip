@@ -34,11 +34,11 @@ struct Knobs {
 
 struct GemmParams {
     const void* A; const void* B; void* C;
-    const float* bias; const void* aux_in; void* aux_out; const float* residual;
+    const float* bias; const void* aux_in; void* aux_out; const void* residual;   // residual: float32, or the operand dtype when res_lowp
     const float* row_scale;        // fp8 path: per-row dequantisation scale of A (multiplies alpha), else NULL
     int M, N, K;
     int64_t lda, ldb, ldc, ld_aux, ldr;
-    int act, out_f32;
+    int act, out_f32, res_lowp;
     int ablate;                    // eavqa_gemm_ex timing-only ablations of the specialised kernels (0 in the product path)
     float alpha;
     int tiles_m, tiles_n;
@@ -122,11 +122,19 @@ __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* 
             for (int j = 0; j < 4; ++j) v[j] = act_fwd(ACT, v[j]);
         }
         if (p.residual) {
-            const float* q = p.residual + (int64_t)m * p.ldr + n;
-            if (FULL || (full && p.vec_res)) { float4 t = *reinterpret_cast<const float4*>(q); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-            else
-                for (int j = 0; j < 4; ++j)
-                    if (n + j < p.N) v[j] += q[j];
+            if (p.res_lowp) {                                  // residual stream kept in the operand dtype (the frozen CLIP tower)
+                const T* q = reinterpret_cast<const T*>(p.residual) + (int64_t)m * p.ldr + n;
+                if (FULL || (full && p.vec_res)) { float4 t = elem<T>::ld4(q); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < p.N) v[j] += elem<T>::ld(q + j);
+            } else {
+                const float* q = reinterpret_cast<const float*>(p.residual) + (int64_t)m * p.ldr + n;
+                if (FULL || (full && p.vec_res)) { float4 t = *reinterpret_cast<const float4*>(q); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < p.N) v[j] += q[j];
+            }
         }
         if (p.out_f32) {
             float* q = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
@@ -995,7 +1003,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(GemmParams p) {
         if (p.aux_out) elem<bf16_t>::st(reinterpret_cast<bf16_t*>(p.aux_out) + ia, v);
         if (p.aux_in) v *= act_bwd(p.act, elem<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p.aux_in) + ia));
         else v = act_fwd(p.act, v);
-        if (p.residual) v += p.residual[(int64_t)m * p.ldr + n];
+        if (p.residual) v += p.res_lowp ? elem<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p.residual) + (int64_t)m * p.ldr + n)
+                                        : reinterpret_cast<const float*>(p.residual)[(int64_t)m * p.ldr + n];
         if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = v;
         else elem<bf16_t>::st(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n, v);
     }
@@ -1160,11 +1169,14 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
 
 extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                              const void* A, int64_t lda, const void* B, int64_t ldb,
-                             void* C, int64_t ldc, int out_f32, float alpha,
+                             void* C, int64_t ldc, int out_flags, float alpha,
                              const float* bias, int act,
                              const void* aux_in, void* aux_out, int64_t ld_aux,
-                             const float* residual, int64_t ldr, void* stream, int knobs) {
+                             const void* residual, int64_t ldr, void* stream, int knobs) {
     const Knobs kn(knobs);
+    if (out_flags & ~(EAVQA_GEMM_OUT_F32 | EAVQA_GEMM_RESIDUAL_LOWP)) return EAVQA_E_ARG;
+    const int out_f32 = out_flags & EAVQA_GEMM_OUT_F32;
+    const int res_lowp = (out_flags & EAVQA_GEMM_RESIDUAL_LOWP) && dtype != EAVQA_F32;      // fp32 operands: the residual is fp32 either way
     if (!A || !B || !C) return EAVQA_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0) return EAVQA_E_ARG;
     if (dtype != EAVQA_F32 && dtype != EAVQA_BF16) return EAVQA_E_DTYPE;
@@ -1182,7 +1194,7 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = nullptr; p.ablate = kn.ablate;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
-    p.act = act; p.out_f32 = out_f32; p.alpha = alpha;
+    p.act = act; p.out_f32 = out_f32; p.res_lowp = res_lowp; p.alpha = alpha;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     const int esz = dtype == EAVQA_BF16 ? 2 : 4;
@@ -1191,7 +1203,7 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     };
     p.vec_c = vec_ok(C, ldc, out_f32 ? 4 : esz);
     p.vec_aux = vec_ok(aux_in ? aux_in : aux_out, ld_aux, esz);
-    p.vec_res = vec_ok(residual, ldr, 4);
+    p.vec_res = vec_ok(residual, ldr, res_lowp ? esz : 4);
     p.vec_bias = (reinterpret_cast<uintptr_t>(bias) % 16) == 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
@@ -1257,11 +1269,11 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
 
 extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                           const void* A, int64_t lda, const void* B, int64_t ldb,
-                          void* C, int64_t ldc, int out_f32, float alpha,
+                          void* C, int64_t ldc, int out_flags, float alpha,
                           const float* bias, int act,
                           const void* aux_in, void* aux_out, int64_t ld_aux,
-                          const float* residual, int64_t ldr, void* stream) {
-    return eavqa_gemm_ex(dtype, a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, out_f32, alpha, bias, act, aux_in, aux_out, ld_aux,
+                          const void* residual, int64_t ldr, void* stream) {
+    return eavqa_gemm_ex(dtype, a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, out_flags, alpha, bias, act, aux_in, aux_out, ld_aux,
                          residual, ldr, stream, 0);
 }
 
@@ -1306,7 +1318,7 @@ extern "C" int eavqa_gemm_fp8(int M, int N, int K, const void* A, int64_t lda, c
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = a_row_scale; p.ablate = 0;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
-    p.act = act; p.out_f32 = out_f32; p.alpha = alpha * b_scale;
+    p.act = act; p.out_f32 = out_f32; p.res_lowp = 0; p.alpha = alpha * b_scale;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     auto vec_ok = [](const void* ptr, int64_t ld, int bytes_per_elem) {

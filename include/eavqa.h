@@ -62,8 +62,12 @@ int eavqa_check_device(void);
  *   if aux_out: aux_out[m,n] = v             (pre-activation, dtype = `dtype`)
  *   v  = act(v)                              (act id above)
  *   if aux_in:  v = v * act'(aux_in[m,n])    (backward of the activation; act() above is skipped)
- *   if residual: v += residual[m,n]          (float32, leading dim ldr; may alias C when out_f32)
- *   C[m,n] = v                               (float32 when out_f32 != 0, else `dtype`)
+ *   if residual: v += residual[m,n]          (float32 - or `dtype` with EAVQA_GEMM_RESIDUAL_LOWP -, leading dim ldr; may alias C
+ *                                             when it has C's element type)
+ *   C[m,n] = v                               (float32 with EAVQA_GEMM_OUT_F32, else `dtype`)
+ * out_flags: EAVQA_GEMM_OUT_F32 (= 1: the historical `out_f32` argument) | EAVQA_GEMM_RESIDUAL_LOWP (= 2: the residual is stored in
+ *   `dtype`: the residual stream of a frozen, forward-only tower kept in bf16 - OpenAI CLIP itself runs its tower in fp16 on the
+ *   GPU, extract_clip_embeddings_conceptual_captions.py:26,86 - halves the epilogue's stream traffic).
  * Replaces: torch.nn.Linear / HF Conv1D matmuls of clipcap.py:31-42 (MLP mapper),
  * :45-104 (mapper transformer), HF:models/gpt2/modeling_gpt2.py:186-226,229-243,698,
  * HF:models/opt/modeling_opt.py:137-181,228-248, HF:models/clip/modeling_clip.py:296-385,
@@ -73,10 +77,10 @@ int eavqa_check_device(void);
  */
 int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                const void* A, int64_t lda, const void* B, int64_t ldb,
-               void* C, int64_t ldc, int out_f32, float alpha,
+               void* C, int64_t ldc, int out_flags, float alpha,
                const float* bias, int act,
                const void* aux_in, void* aux_out, int64_t ld_aux,
-               const float* residual, int64_t ldr, void* stream);
+               const void* residual, int64_t ldr, void* stream);
 
 /* ----------------------------------------------------------- LayerNorm ---
  * torch.nn.LayerNorm over the last dim (ln_1/ln_2/ln_f HF:gpt2 :253-257,620;

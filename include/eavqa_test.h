@@ -31,7 +31,9 @@ int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                   const float* residual, int64_t ldr, void* stream, int knobs);
 
 /* eavqa_attention_fwd / _bwd with a path selector: bit 0 keeps bf16 on the vector-ALU kernels (instead of the matrix-core
- * ones), bit 1 (backward) takes the dQ + dK/dV kernel pair even when the problem is one tile. */
+ * ones), bit 1 (backward) takes the dQ + dK/dV kernel pair even when the problem is one tile, bit 2 (forward) keeps the
+ * streamed-tile matrix-core kernel where the K / V-resident one (hd 64, no mask, Sq == Sk <= 592) would be chosen, bit 3 (forward)
+ * takes the resident kernel also for Sk <= 64. */
 int eavqa_attention_fwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
                            const void* q, int64_t ldq, const void* k, int64_t ldk,
                            const void* v, int64_t ldv, void* o, int64_t ldo,

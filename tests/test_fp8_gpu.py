@@ -206,12 +206,14 @@ def test_fp8_lm_training_step_against_weight_roundtripped_oracle(arch):
     # are what a wrong dgrad cannot pass (zero gradient: ratio 0; sign error: cosine -1; a wrong scale or a transposed weight: cosine
     # near 0); max-rel of the largest entry is printed only.  CPU numerics model of the same dataflow (tests/test_fp8_numerics_model.py):
     # cosine 0.988 (OPT: e4m3 forward activations flip ReLU derivatives) / 0.999 (GPT-2) against the round-tripped fp32 oracle.
+    # Measured on MI355X (round 3): bf16 0.9976 / 0.9999; fp8 vs the format-cost oracle 0.9784 / 0.9961; fp8 vs the numerics model
+    # 0.9767 / 0.9949; norm ratios 0.988 .. 1.000.
     relu = arch == "opt"
     cases = (("native", "bf16 LM vs fp32 oracle", sd, base, dict(loss=5e-3, logits=8e-2, cos=0.995 if relu else 0.9995, ratio=0.02)),
              ("fp8", "fp8 LM vs fp32 oracle with e4m3-round-tripped weights (what the FORMAT costs)", wq, base,
-              dict(loss=2e-2, logits=0.6, cos=0.96 if relu else 0.995, ratio=0.05)),
+              dict(loss=2e-2, logits=0.6, cos=0.96 if relu else 0.99, ratio=0.03)),
              ("fp8", "fp8 LM vs the fp8 numerics model (oracle/fp8_sim.py: same quantisation points, fp32 elsewhere)", wq,
-              dict(base, linear_fn=fp8_sim.fp8_linear), dict(loss=2e-2, logits=0.6, cos=0.96 if relu else 0.995, ratio=0.05)))
+              dict(base, linear_fn=fp8_sim.fp8_linear), dict(loss=2e-2, logits=0.6, cos=0.96 if relu else 0.99, ratio=0.03)))
     for fmt, what, wsd, ocfg, tol in cases:
         mp = {k: v.clone().requires_grad_(True) for k, v in mapper_sd.items()}
         loss, logits = oracle.clipcap_forward(wsd, ocfg, mp, dict(prefix_length=L, mapping_type="mlp"), ids, prefix, mask, labels)
@@ -270,7 +272,8 @@ def test_fp8_and_bf16_lm_train_the_mapper_alike(arch):
     gap = (a - b).abs().max().item()
     print(f"[{arch}] 30 steps: bf16 loss {a[0]:.4f} -> {a[-1]:.4f}, fp8 loss {b[0]:.4f} -> {b[-1]:.4f}, max |gap| {gap:.4f} = {100 * gap / drop:.1f} % of the bf16 drop")
     assert drop > 0.3, "the bf16 run must actually train for the comparison to mean anything"
-    assert (b[0] - b[-1]).item() >= 0.85 * drop and gap <= 0.15 * drop, (curves, gap, drop)
+    # measured on MI355X: max gap 1.2 % (OPT) / 0.7 % (GPT-2) of the bf16 drop
+    assert (b[0] - b[-1]).item() >= 0.95 * drop and gap <= 0.05 * drop, (curves, gap, drop)
 
 
 def test_fp8_lm_generate_defaults_fall_back_to_the_uncached_loop():

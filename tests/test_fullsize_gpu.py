@@ -322,4 +322,5 @@ def test_cfg5_fp8_training_step_real_size():
     # direction and length of the WHOLE mapper gradient: what a wrong dgrad cannot pass (zero: ratio 0; sign error: cosine -1; wrong
     # scale / transposed weight: cosine ~ 0).  The max-rel of the largest entry (0.45 measured) is printed, not judged: e4m3 forward
     # activations flip ReLU derivatives through 32 layers (tests/test_fp8_numerics_model.py: the gradient operand's format is not the cause)
-    assert cos >= 0.85 and 0.85 <= ratio <= 1.18, (cos, ratio)
+    # measured on MI355X (round 3): cosine 0.926, norm ratio 1.005
+    assert cos >= 0.88 and 0.93 <= ratio <= 1.07, (cos, ratio)

@@ -334,6 +334,52 @@ def test_attention_forward_backward(ops, attn_path, dtype, B, H, Sq, Sk, hd, cau
         assert (got.float().cpu().reshape(want.shape) - want.float()).abs().max().item() <= tb * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("B,H,N", [(3, 4, 257), (2, 3, 577), (2, 2, 50), (1, 2, 65), (1, 3, 97), (1, 2, 592), (2, 1, 33), (1, 1, 1), (5, 2, 288), (1, 2, 321)])
+def test_attention_resident_kv_kernel_bf16(ops, B, H, N):
+    """The K / V-resident forward (eavqa_attn_mfma::fwd_resident64_kernel: the CLIP tower's attention, hd 64, no mask) against the
+    float64 reference and against the streamed-tile kernel on the same fused [B*N, 3E] qkv rows: every tail shape (N = 32 k + 1,
+    32 k, one tile, two workgroup-size classes, a lone last query block riding on wave 0), output and log-sum-exp."""
+    hd = 64
+    E = H * hd
+    q, k, v = (rnd(B, N, H, hd, dtype=torch.bfloat16, seed=s) for s in (1, 2, 3))
+    ref = attn_ref(q.double(), k.double(), v.double(), None, False, hd ** -0.5)
+    sc = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * hd ** -0.5
+    lse_ref = torch.logsumexp(sc, -1)                                           # [B, H, N]
+    qkv = torch.cat([q.reshape(B * N, E), k.reshape(B * N, E), v.reshape(B * N, E)], dim=1).to(DEV)
+    Q, K, V = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
+    outs = {}
+    for name, path in (("resident", 8), ("streamed", 4)):
+        ops.KernelSelect.attention = path
+        try:
+            o, lse = ops.attention_fwd(Q, K, V, B, H, N, N, hd, causal=False, scale=hd ** -0.5, save_lse=True)
+        finally:
+            ops.KernelSelect.attention = 0
+        outs[name] = o.float().cpu()
+        assert (outs[name].reshape(B, N, H, hd) - ref.float()).abs().max().item() <= 2e-2, name
+        assert (lse.cpu().double() - lse_ref).abs().max().item() <= 2e-2, name
+    assert (outs["resident"] - outs["streamed"]).abs().max().item() <= 2e-2
+    # exact data: one-hot attention (a huge score on one key per query) must copy that key's V row bit for bit
+    sel = torch.randint(0, N, (B, N), generator=torch.Generator().manual_seed(9))
+    kk = torch.zeros(B, N, H, hd)
+    kk[..., 0] = torch.arange(N)[None, :, None].float() / 4.0                   # key j carries j / 4 in feature 0 (exact in bf16 up to 1024 / 4)
+    # query i asks for key sel[i]: score = 64 * (2 t k - k^2) / 4 ... peaked at k = t; built directly as a two-feature parabola
+    qq = torch.zeros(B, N, H, hd)
+    t = sel[..., None].float() / 4.0
+    qq[..., 0] = 2.0 * t * 64.0
+    qq[..., 1] = -64.0
+    kk[..., 1] = kk[..., 0] ** 2
+    if N <= 512:                                                                 # (j / 4)^2 stays exact in bf16 only for small j
+        vv = rnd(B, N, H, hd, dtype=torch.bfloat16, seed=5)
+        qkv2 = torch.cat([qq.bfloat16().reshape(B * N, E), kk.bfloat16().reshape(B * N, E), vv.reshape(B * N, E)], dim=1).to(DEV)
+        ops.KernelSelect.attention = 8
+        try:
+            o2 = ops.attention_fwd(qkv2[:, :E], qkv2[:, E:2 * E], qkv2[:, 2 * E:], B, H, N, N, hd, causal=False, scale=1.0)
+        finally:
+            ops.KernelSelect.attention = 0
+        refq = attn_ref(qq.bfloat16().double(), kk.bfloat16().double(), vv.double(), None, False, 1.0)
+        assert (o2.float().cpu().reshape(B, N, H, hd) - refq.float()).abs().max().item() <= 2e-2
+
+
 @pytest.mark.parametrize("B,H,S,hd", [(2, 2, 42, 200), (1, 3, 64, 640), (2, 1, 5, 136)])
 def test_attention_wide_heads_ragged_chunk_bf16(ops, B, H, S, hd):
     """Head dims the vector-ALU kernels do not cover (GPT-2-xl mapper 1600 / 8 = 200, OPT-13B 5120 / 8 = 640): bf16 only, the last
