@@ -45,6 +45,24 @@ template <> struct elem<bf16_t> {
     }
 };
 
+// IEEE half: a STORAGE type of the frozen CLIP tower's residual stream only (EAVQA_F16: LayerNorm input / output, GEMM residual / C);
+// no kernel multiplies in it.
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+template <> struct elem<f16_t> {
+    static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+    static __device__ __forceinline__ float4 ld4(const f16_t* p) {
+        f16x4 t = *reinterpret_cast<const f16x4*>(p);
+        return make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]);
+    }
+    static __device__ __forceinline__ void st4(f16_t* p, float4 v) {
+        f16x4 t;
+        t[0] = (f16_t)v.x; t[1] = (f16_t)v.y; t[2] = (f16_t)v.z; t[3] = (f16_t)v.w;
+        *reinterpret_cast<f16x4*>(p) = t;
+    }
+};
+
 // ---- activations (forward value and derivative w.r.t. the pre-activation) ----
 // tanh through one v_exp + one v_rcp: tanh(x) = 1 - 2 / (exp(2x) + 1).  |error| <= ~2e-7 absolute (exp2-based
 // __expf is within 2 ulp, the form is stable at both tails: exp -> inf gives 1, exp -> 0 gives -1).  The libm

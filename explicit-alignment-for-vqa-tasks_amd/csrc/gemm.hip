@@ -38,7 +38,8 @@ struct GemmParams {
     const float* row_scale;        // fp8 path: per-row dequantisation scale of A (multiplies alpha), else NULL
     int M, N, K;
     int64_t lda, ldb, ldc, ld_aux, ldr;
-    int act, out_f32, res_lowp;
+    int act, out_f32, res_lowp;   // res_lowp: 0 float32 residual, 1 operand dtype, 2 half
+    int out_f16;                  // C (when not float32) is half instead of the operand dtype
     int ablate;                    // eavqa_gemm_ex timing-only ablations of the specialised kernels (0 in the product path)
     float alpha;
     int tiles_m, tiles_n;
@@ -122,7 +123,13 @@ __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* 
             for (int j = 0; j < 4; ++j) v[j] = act_fwd(ACT, v[j]);
         }
         if (p.residual) {
-            if (p.res_lowp) {                                  // residual stream kept in the operand dtype (the frozen CLIP tower)
+            if (p.res_lowp == 2) {                             // 16-bit residual stream of a frozen tower (the CLIP tower): half ...
+                const f16_t* q = reinterpret_cast<const f16_t*>(p.residual) + (int64_t)m * p.ldr + n;
+                if (FULL || (full && p.vec_res)) { float4 t = elem<f16_t>::ld4(q); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+                else
+                    for (int j = 0; j < 4; ++j)
+                        if (n + j < p.N) v[j] += elem<f16_t>::ld(q + j);
+            } else if (p.res_lowp) {                           // ... or the operand dtype
                 const T* q = reinterpret_cast<const T*>(p.residual) + (int64_t)m * p.ldr + n;
                 if (FULL || (full && p.vec_res)) { float4 t = elem<T>::ld4(q); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
                 else
@@ -142,6 +149,12 @@ __device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* 
             else
                 for (int j = 0; j < 4; ++j)
                     if (n + j < p.N) q[j] = v[j];
+        } else if (p.out_f16) {
+            f16_t* q = reinterpret_cast<f16_t*>(p.C) + (int64_t)m * p.ldc + n;
+            if (FULL || (full && p.vec_c)) elem<f16_t>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
+            else
+                for (int j = 0; j < 4; ++j)
+                    if (n + j < p.N) elem<f16_t>::st(q + j, v[j]);
         } else {
             T* q = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
             if (FULL || (full && p.vec_c)) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
@@ -1003,9 +1016,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_skinny_kernel(GemmParams p) {
         if (p.aux_out) elem<bf16_t>::st(reinterpret_cast<bf16_t*>(p.aux_out) + ia, v);
         if (p.aux_in) v *= act_bwd(p.act, elem<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p.aux_in) + ia));
         else v = act_fwd(p.act, v);
-        if (p.residual) v += p.res_lowp ? elem<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p.residual) + (int64_t)m * p.ldr + n)
-                                        : reinterpret_cast<const float*>(p.residual)[(int64_t)m * p.ldr + n];
+        if (p.residual) v += p.res_lowp == 2 ? elem<f16_t>::ld(reinterpret_cast<const f16_t*>(p.residual) + (int64_t)m * p.ldr + n)
+                             : p.res_lowp ? elem<bf16_t>::ld(reinterpret_cast<const bf16_t*>(p.residual) + (int64_t)m * p.ldr + n)
+                                          : reinterpret_cast<const float*>(p.residual)[(int64_t)m * p.ldr + n];
         if (p.out_f32) reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = v;
+        else if (p.out_f16) elem<f16_t>::st(reinterpret_cast<f16_t*>(p.C) + (int64_t)m * p.ldc + n, v);
         else elem<bf16_t>::st(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n, v);
     }
 }
@@ -1174,9 +1189,11 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                              const void* aux_in, void* aux_out, int64_t ld_aux,
                              const void* residual, int64_t ldr, void* stream, int knobs) {
     const Knobs kn(knobs);
-    if (out_flags & ~(EAVQA_GEMM_OUT_F32 | EAVQA_GEMM_RESIDUAL_LOWP)) return EAVQA_E_ARG;
+    if (out_flags & ~(EAVQA_GEMM_OUT_F32 | EAVQA_GEMM_RESIDUAL_LOWP | EAVQA_GEMM_STREAM_F16)) return EAVQA_E_ARG;
+    if ((out_flags & (EAVQA_GEMM_RESIDUAL_LOWP | EAVQA_GEMM_STREAM_F16)) && dtype != EAVQA_BF16) return EAVQA_E_DTYPE;   // 16-bit streams: bf16 operands only
     const int out_f32 = out_flags & EAVQA_GEMM_OUT_F32;
-    const int res_lowp = (out_flags & EAVQA_GEMM_RESIDUAL_LOWP) && dtype != EAVQA_F32;      // fp32 operands: the residual is fp32 either way
+    const int stream_f16 = (out_flags & EAVQA_GEMM_STREAM_F16) != 0;
+    const int res_lowp = (out_flags & EAVQA_GEMM_RESIDUAL_LOWP) ? (stream_f16 ? 2 : 1) : 0;
     if (!A || !B || !C) return EAVQA_E_ARG;
     if (M <= 0 || N <= 0 || K <= 0) return EAVQA_E_ARG;
     if (dtype != EAVQA_F32 && dtype != EAVQA_BF16) return EAVQA_E_DTYPE;
@@ -1194,7 +1211,7 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = nullptr; p.ablate = kn.ablate;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
-    p.act = act; p.out_f32 = out_f32; p.res_lowp = res_lowp; p.alpha = alpha;
+    p.act = act; p.out_f32 = out_f32; p.res_lowp = res_lowp; p.out_f16 = stream_f16 && !out_f32; p.alpha = alpha;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     const int esz = dtype == EAVQA_BF16 ? 2 : 4;
@@ -1318,7 +1335,7 @@ extern "C" int eavqa_gemm_fp8(int M, int N, int K, const void* A, int64_t lda, c
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = a_row_scale; p.ablate = 0;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
-    p.act = act; p.out_f32 = out_f32; p.res_lowp = 0; p.alpha = alpha * b_scale;
+    p.act = act; p.out_f32 = out_f32; p.res_lowp = 0; p.out_f16 = 0; p.alpha = alpha * b_scale;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     auto vec_ok = [](const void* ptr, int64_t ld, int bytes_per_elem) {

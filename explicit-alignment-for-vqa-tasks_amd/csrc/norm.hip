@@ -9,9 +9,12 @@ namespace {
 constexpr int LN_MAX_V4 = 32;  // float4 per lane: cols <= 64 * 4 * 32 = 8192
 constexpr int LN_WAVES = 4;    // rows per 256-thread block
 
+// kind: 0 = T, 1 = float32, 2 = bfloat16, 3 = half (wave-uniform)
 template <typename T>
-__device__ __forceinline__ float4 ldrow4(const void* base, int64_t off, bool f32) {
-    if (f32) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+__device__ __forceinline__ float4 ldrow4(const void* base, int64_t off, int kind) {
+    if (kind == 1) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+    if (kind == 2) return elem<bf16_t>::ld4(reinterpret_cast<const bf16_t*>(base) + off);
+    if (kind == 3) return elem<f16_t>::ld4(reinterpret_cast<const f16_t*>(base) + off);
     return elem<T>::ld4(reinterpret_cast<const T*>(base) + off);
 }
 
@@ -191,15 +194,17 @@ int ln_bwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, c
 
 }  // namespace
 
-extern "C" int eavqa_layernorm_fwd(int dtype, int x_f32, int rows, int cols, const void* x, int64_t ldx,
+extern "C" int eavqa_layernorm_fwd(int dtype, int x_kind, int rows, int cols, const void* x, int64_t ldx,
                                    const float* gamma, const float* beta, float eps, void* y, int64_t ldy,
                                    float* mean, float* rstd, void* stream) {
     if (!x || !y || rows <= 0 || cols <= 0) return EAVQA_E_ARG;
     if (cols % 4 || cols > 64 * 4 * LN_MAX_V4) return EAVQA_E_SHAPE;
     if (ldx % 4 || ldy % 4) return EAVQA_E_ALIGN;
+    if (x_kind < 0 || x_kind > 3) return EAVQA_E_DTYPE;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (dtype == EAVQA_F32) return ln_fwd_dispatch<float>(1, rows, cols, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, s);
-    if (dtype == EAVQA_BF16) return ln_fwd_dispatch<bf16_t>(x_f32, rows, cols, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, s);
+    if (dtype == EAVQA_F32) return ln_fwd_dispatch<float>(x_kind == 0 ? 1 : x_kind, rows, cols, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, s);
+    if (dtype == EAVQA_BF16) return ln_fwd_dispatch<bf16_t>(x_kind, rows, cols, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, s);
+    if (dtype == EAVQA_F16) return ln_fwd_dispatch<f16_t>(x_kind, rows, cols, x, ldx, gamma, beta, eps, y, ldy, mean, rstd, s);
     return EAVQA_E_DTYPE;
 }
 

@@ -77,8 +77,23 @@ def random_init_vit_state_dict(cfg: ViTConfig, seed: int = 2021, device="cpu") -
 class ClipVisionEncoder:
     """Frozen CLIP ViT: ``encode_image(pixels [B,3,H,W] float32) -> float32 [B, D]``."""
 
-    def __init__(self, cfg: ViTConfig, state_dict: Dict[str, Tensor], dtype: torch.dtype = torch.bfloat16, device="cuda"):
+    def __init__(self, cfg: ViTConfig, state_dict: Dict[str, Tensor], dtype: torch.dtype = torch.bfloat16, device="cuda",
+                 stream_dtype: torch.dtype = None):
+        """``stream_dtype``: storage type of the residual stream.  The tower is frozen and forward-only, so with bf16 operands the
+        stream is kept in 16 bits: the out-projection / FFN-down epilogues and both LayerNorms then move half the bytes of a float32
+        stream (round 2: 2 x 168 MB per launch at 160 images).  Default in bf16 mode: ``torch.float16`` - what OpenAI CLIP itself holds
+        on the GPU (the whole tower in fp16, extract_clip_embeddings_conceptual_captions.py:26,86): 11 significant bits, so the
+        2 x n_layer roundings of the residual sums stay below the bf16 operands' own error (measured on MI355X, ViT-L/14, max |d
+        image_embeds| against the fp32 oracle: float32 stream 1.6e-2, bfloat16 stream 3.4e-2).  ``torch.bfloat16`` and
+        ``torch.float32`` (the round-2 stream) are accepted too; fp32 mode always streams in float32."""
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        if stream_dtype is None:
+            stream_dtype = torch.float16 if dtype == torch.bfloat16 else torch.float32
+        self.stream_dtype = stream_dtype
+        if dtype == torch.float32 and stream_dtype != torch.float32:
+            raise ValueError("fp32 mode streams in float32")
+        if stream_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise ValueError("stream_dtype must be float32, bfloat16 or float16")
         T = lambda t: t.to(device=self.device, dtype=dtype).contiguous()
         F = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         p = "vision_model."
@@ -117,14 +132,16 @@ class ClipVisionEncoder:
         patches = ops.patchify(pixels.to(self.device), c.patch, T, self.kpad)
         pe = ops.gemm(patches, self.w_patch)
         x = ops.vit_assemble(pe, self.cls, self.pos, B, c.n_patch)
-        x = ops.layernorm_fwd(x, self.pre_g, self.pre_b, c.eps, torch.float32)     # the residual stream stays fp32
+        ST = self.stream_dtype
+        x = ops.layernorm_fwd(x, self.pre_g, self.pre_b, c.eps, ST)                # the residual stream: ``stream_dtype``
+        x1 = torch.empty_like(x)
         for L in self.layers:
             a = ops.layernorm_fwd(x, L["ln1_g"], L["ln1_b"], c.eps, T)
             qkv = ops.gemm(a, L["w_qkv"], bias=L["b_qkv"])
             ctx = ops.attention_fwd(qkv[:, :W], qkv[:, W:2 * W], qkv[:, 2 * W:], B, H, N, N, hd, causal=False, scale=hd ** -0.5)
-            x1 = ops.gemm(ctx, L["w_o"], bias=L["b_o"], residual=x, out_f32=True)
+            ops.gemm(ctx, L["w_o"], bias=L["b_o"], residual=x, out=x1)
             a2 = ops.layernorm_fwd(x1, L["ln2_g"], L["ln2_b"], c.eps, T)
             f = ops.gemm(a2, L["w_fc1"], bias=L["b_fc1"], act=c.act)
-            x = ops.gemm(f, L["w_fc2"], bias=L["b_fc2"], residual=x1, out_f32=True)
+            ops.gemm(f, L["w_fc2"], bias=L["b_fc2"], residual=x1, out=x)
         pooled = ops.layernorm_fwd(x.view(B, N, W)[:, 0], self.post_g, self.post_b, c.eps, T)
         return ops.gemm(pooled, self.w_proj, out_f32=True)

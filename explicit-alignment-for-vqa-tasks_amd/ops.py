@@ -15,11 +15,16 @@ from ._lib import ACT, BF16, F32, call
 Tensor = torch.Tensor
 
 
-def dtype_id(dt: torch.dtype) -> int:
+F16 = 2   # EAVQA_F16: storage type of a frozen tower's residual stream only (layernorm_fwd x / y, gemm residual / out)
+
+
+def dtype_id(dt: torch.dtype, stream: bool = False) -> int:
     if dt == torch.float32:
         return F32
     if dt == torch.bfloat16:
         return BF16
+    if stream and dt == torch.float16:
+        return F16
     raise _lib.EavqaError(f"unsupported storage dtype {dt}")
 
 
@@ -68,14 +73,25 @@ def gemm(a: Tensor, b: Tensor, *, a_kc: bool = True, b_kc: bool = True, bias: Op
     if a.dtype != b.dtype:
         raise _lib.EavqaError("gemm operands must share a dtype")
     dt = dtype_id(a.dtype)
+    half = torch.float16                                    # 16-bit stream of a frozen tower (bf16 operands): EAVQA_GEMM_STREAM_F16
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32 if out_f32 else a.dtype)
-    elif out.dtype != torch.float32 and out.dtype != a.dtype:
-        raise _lib.EavqaError("gemm out dtype must be float32 or the operand dtype")
+    elif out.dtype != torch.float32 and out.dtype != a.dtype and not (out.dtype == half and a.dtype == torch.bfloat16):
+        raise _lib.EavqaError("gemm out dtype must be float32, the operand dtype or (bf16 operands) float16")
     out_f32 = out.dtype == torch.float32
     aux = aux_in if aux_in is not None else aux_out
+    flags = int(out_f32)                                    # EAVQA_GEMM_OUT_F32
+    if residual is not None and residual.dtype != torch.float32:
+        if residual.dtype != a.dtype and not (residual.dtype == half and a.dtype == torch.bfloat16):
+            raise _lib.EavqaError("gemm residual must be float32, the operand dtype or (bf16 operands) float16")
+        flags |= 2                                          # EAVQA_GEMM_RESIDUAL_LOWP: the residual stream of a frozen tower in 16 bits
+    stream_half = (out.dtype == half) or (residual is not None and residual.dtype == half)
+    if stream_half:
+        if (out.dtype not in (half, torch.float32)) or (residual is not None and residual.dtype not in (half, torch.float32)):
+            raise _lib.EavqaError("gemm: a float16 stream needs float16 (or float32) for both the residual and the output")
+        flags |= 4                                          # EAVQA_GEMM_STREAM_F16
     args = (dt, int(a_kc), int(b_kc), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out),
-            int(out_f32), float(alpha), _p(bias), ACT[act], _p(aux_in), _p(aux_out), _ld(aux) if aux is not None else 0,
+            flags, float(alpha), _p(bias), ACT[act], _p(aux_in), _p(aux_out), _ld(aux) if aux is not None else 0,
             _p(residual), _ld(residual) if residual is not None else 0, _stream())
     if KernelSelect.gemm:
         call("eavqa_gemm_ex", *args, KernelSelect.gemm)
@@ -115,7 +131,8 @@ def gemm_fp8(a_q: Tensor, a_scale: Tensor, b_q: Tensor, b_scale: float, *, bias:
 
 def layernorm_fwd(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float, out_dtype: torch.dtype,
                   save_stats: bool = False, out: Optional[Tensor] = None):
-    """Rows of ``x`` ([rows, cols], float32 or ``out_dtype``) -> ``y`` in ``out_dtype`` (+ mean, rstd)."""
+    """Rows of ``x`` ([rows, cols]: float32, bfloat16 or float16) -> ``y`` in ``out_dtype`` (+ mean, rstd).  float16 is the storage
+    type of a frozen tower's residual stream only (models/clip_vit.py)."""
     _dev(x)
     rows, cols = x.shape
     y = out if out is not None else torch.empty((rows, cols), device=x.device, dtype=out_dtype)
@@ -123,7 +140,10 @@ def layernorm_fwd(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ep
     if save_stats:
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-    call("eavqa_layernorm_fwd", dtype_id(out_dtype), int(x.dtype == torch.float32), rows, cols, _p(x), _ld(x),
+    x_kind = {torch.float32: 1, torch.bfloat16: 2, torch.float16: 3}.get(x.dtype)
+    if x_kind is None:
+        raise _lib.EavqaError(f"unsupported layernorm input dtype {x.dtype}")
+    call("eavqa_layernorm_fwd", dtype_id(out_dtype, stream=True), x_kind, rows, cols, _p(x), _ld(x),
          _p(gamma), _p(beta), float(eps), _p(y), _ld(y), _p(mean), _p(rstd), _stream())
     return (y, mean, rstd) if save_stats else y
 

@@ -32,9 +32,12 @@ extern "C" {
 
 #define EAVQA_ABI_VERSION 1
 
-enum { EAVQA_F32 = 0, EAVQA_BF16 = 1 };
+enum { EAVQA_F32 = 0, EAVQA_BF16 = 1,
+       EAVQA_F16 = 2 };   /* IEEE half: only as the STORAGE type of a frozen tower's residual stream (eavqa_layernorm_fwd x / y,
+                             eavqa_gemm residual / C with EAVQA_GEMM_STREAM_F16); no kernel multiplies in it */
 
 /* activation ids (HF:activations.py: gelu_new :59-66, quick_gelu :117-123; torch tanh/relu) */
+enum { EAVQA_GEMM_OUT_F32 = 1, EAVQA_GEMM_RESIDUAL_LOWP = 2, EAVQA_GEMM_STREAM_F16 = 4 };     /* eavqa_gemm out_flags */
 enum { EAVQA_ACT_NONE = 0, EAVQA_ACT_TANH = 1, EAVQA_ACT_RELU = 2, EAVQA_ACT_GELU_NEW = 3, EAVQA_ACT_QUICK_GELU = 4 };
 
 enum {
@@ -65,9 +68,11 @@ int eavqa_check_device(void);
  *   if residual: v += residual[m,n]          (float32 - or `dtype` with EAVQA_GEMM_RESIDUAL_LOWP -, leading dim ldr; may alias C
  *                                             when it has C's element type)
  *   C[m,n] = v                               (float32 with EAVQA_GEMM_OUT_F32, else `dtype`)
- * out_flags: EAVQA_GEMM_OUT_F32 (= 1: the historical `out_f32` argument) | EAVQA_GEMM_RESIDUAL_LOWP (= 2: the residual is stored in
- *   `dtype`: the residual stream of a frozen, forward-only tower kept in bf16 - OpenAI CLIP itself runs its tower in fp16 on the
- *   GPU, extract_clip_embeddings_conceptual_captions.py:26,86 - halves the epilogue's stream traffic).
+ * out_flags: EAVQA_GEMM_OUT_F32 (= 1: the historical `out_f32` argument) | EAVQA_GEMM_RESIDUAL_LOWP (= 2: the residual is a 16-bit
+ *   type, not float32: the residual stream of a frozen, forward-only tower - halves the epilogue's stream traffic) |
+ *   EAVQA_GEMM_STREAM_F16 (= 4: that 16-bit residual, and C when it is not float32, are IEEE half instead of `dtype`; bf16 operands
+ *   only.  OpenAI CLIP itself runs its whole tower in fp16 on the GPU, extract_clip_embeddings_conceptual_captions.py:26,86; a
+ *   bf16 stream rounds each of the 2 x n_layer residual sums to 8 bits and doubled the embedding error, half does not).
  * Replaces: torch.nn.Linear / HF Conv1D matmuls of clipcap.py:31-42 (MLP mapper),
  * :45-104 (mapper transformer), HF:models/gpt2/modeling_gpt2.py:186-226,229-243,698,
  * HF:models/opt/modeling_opt.py:137-181,228-248, HF:models/clip/modeling_clip.py:296-385,
@@ -86,10 +91,11 @@ int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
  * torch.nn.LayerNorm over the last dim (ln_1/ln_2/ln_f HF:gpt2 :253-257,620;
  * self_attn_layer_norm/final_layer_norm HF:opt :196-205; CLIP layer_norm1/2, pre/post
  * HF:clip :340-343,909-912; mapper norm1/norm2 clipcap.py:131-135).
- * x: float32 when x_f32 != 0 else `dtype`; y: `dtype`.  mean/rstd (float32 [rows]) may be
+ * y: `dtype` (EAVQA_F32 / EAVQA_BF16 / EAVQA_F16).  x: float32 when x_kind == 1, `dtype` when 0, and explicitly bfloat16 / half
+ * when x_kind == 2 / 3 (a half stream normalised into a bf16 GEMM operand).  mean/rstd (float32 [rows]) may be
  * NULL in inference.  gamma/beta float32 [cols].  cols % 4 == 0, cols <= 8192.
  */
-int eavqa_layernorm_fwd(int dtype, int x_f32, int rows, int cols, const void* x, int64_t ldx,
+int eavqa_layernorm_fwd(int dtype, int x_kind, int rows, int cols, const void* x, int64_t ldx,
                         const float* gamma, const float* beta, float eps,
                         void* y, int64_t ldy, float* mean, float* rstd, void* stream);
 /* dx[r,:] = (dres ? dres[r,:] : 0) + LayerNorm'(dy)[r,:]   (float32 out; dres may alias dx)

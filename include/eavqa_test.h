@@ -25,10 +25,10 @@ extern "C" {
  *   [20:18] round-1 shaped tiles: 0 by cost model, 1 never, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192 */
 int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                   const void* A, int64_t lda, const void* B, int64_t ldb,
-                  void* C, int64_t ldc, int out_f32, float alpha,
+                  void* C, int64_t ldc, int out_flags, float alpha,
                   const float* bias, int act,
                   const void* aux_in, void* aux_out, int64_t ld_aux,
-                  const float* residual, int64_t ldr, void* stream, int knobs);
+                  const void* residual, int64_t ldr, void* stream, int knobs);
 
 /* eavqa_attention_fwd / _bwd with a path selector: bit 0 keeps bf16 on the vector-ALU kernels (instead of the matrix-core
  * ones), bit 1 (backward) takes the dQ + dK/dV kernel pair even when the problem is one tile, bit 2 (forward) keeps the
