@@ -15,200 +15,11 @@
 //     wave so that every wave issues the same NDMA pieces per stage and the counted waits stay exact;
 //   * rows beyond M / N are clamped to the last valid row (their products only reach outputs that are never stored);
 //   * C leaves through the ring's LDS in passes of whole wave rows (16-byte row-contiguous global accesses, shared epilogue).
-template <int WM, int WN, int MF, int NF, int NST_, bool DB_> struct K64Geo {
-    static constexpr int NST = NST_;
-    static constexpr bool DB = DB_;
-    static constexpr int NT = 64 * WM * WN, NW = WM * WN;
-    static constexpr int TBM = 16 * MF * WM, TBN = 16 * NF * WN;
-    static constexpr int AFULL = 8 * TBM / NT, BFULL = 8 * TBN / NT;
-    static constexpr int BREM = (8 * TBN - BFULL * NT) / NW;             // lanes of the partial B piece per wave
-    static constexpr int NDMA = AFULL + BFULL + (BREM > 0 ? 1 : 0);      // DMA instructions per wave and stage
-    static constexpr int AOPER = TBM * 128, STAGE = (TBM + TBN) * 128, RING = NST * STAGE;
-    static constexpr int PITCH = TBN + 4;
-    // C staging: SP whole wave rows per pass, or (one wave row too big for the ring) MFC of its MF fragment rows
-    static constexpr int SP = (16 * MF * WM * PITCH * 4 <= RING) ? WM : ((16 * MF * (WM / 2) * PITCH * 4 <= RING && WM >= 2) ? WM / 2 : 1);
-    static constexpr int MFC = (16 * MF * PITCH * 4 <= RING) ? MF : MF / 2;
-    static constexpr int PROWS = 16 * MFC * SP;
-    static constexpr int TPR = TBN / 4, RPP = NT / TPR, NPASS = (PROWS + RPP - 1) / RPP;
-    static_assert(8 * TBM == AFULL * NT, "A stage must split into whole pieces");
-    static_assert(BFULL * NT + BREM * NW == 8 * TBN && BREM < 64 && BREM % 8 == 0, "B stage: full pieces + one partial piece of whole rows per wave");
-    static_assert(16 * MFC * PITCH * 4 <= RING && MF % MFC == 0 && (MFC == MF || SP == 1), "C staging pass must fit the ring");
-    static_assert(WM % SP == 0, "passes cover whole wave rows");
-    static_assert(RING <= 160 * 1024, "ring exceeds the LDS of a CU");
-    static_assert(NDMA * (NST - 1) <= 63 && NST >= 2 && NST <= 4, "vmcnt field / wait_tiles cover 2..4 stages");
-};
-
 template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(vm_only(N)); }
 
-template <int WM, int WN, int MF, int NF, int NST, bool DB>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4 && NST * (16 * MF * WM + 16 * NF * WN) * 128 <= 80 * 1024) ? 2 : 1)
-void gemm_bf16_k64_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
-    using G = K64Geo<WM, WN, MF, NF, NST, DB>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    int tm, tn;
-    if (!shaped_tile(gx, gy, tiles_m, tiles_n, tm, tn)) return;
-    const int m0 = tm * G::TBM, n0 = tn * G::TBN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A);
-    const bf16_t* B = reinterpret_cast<const bf16_t*>(p.B);
-
-    // per-lane DMA sources; chunk c of an operand image is (row c >> 3, physical 16-byte slot c & 7)
-    auto src_of = [&](const bf16_t* X, int64_t ld, int row0, int rows_max, int c) {
-        const int row = c >> 3, pc = c & 7;
-        return X + (int64_t)min(row0 + row, rows_max - 1) * ld + (pc ^ (row & 7)) * 8;
-    };
-    const bf16_t* asrc[G::AFULL];
-    const bf16_t* bsrc[G::BFULL + 1];
-#pragma unroll
-    for (int i = 0; i < G::AFULL; ++i) asrc[i] = src_of(A, p.lda, m0, p.M, tid + G::NT * i);
-#pragma unroll
-    for (int i = 0; i < G::BFULL; ++i) bsrc[i] = src_of(B, p.ldb, n0, p.N, tid + G::NT * i);
-    bsrc[G::BFULL] = src_of(B, p.ldb, n0, p.N, G::BFULL * G::NT + wave * G::BREM + min(lane, max(G::BREM, 1) - 1));
-    const int dma_off = wave * 1024;                                        // + i * NT * 16 for full pieces
-    const int dma_off_x = G::AOPER + G::BFULL * G::NT * 16 + wave * G::BREM * 16;
-
-    auto issue = [&](int kt, int stage) {
-        char* st = smem + stage * G::STAGE;
-#pragma unroll
-        for (int i = 0; i < G::AFULL; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + kt * 64),
-                                             (__attribute__((address_space(3))) void*)(st + dma_off + i * G::NT * 16), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < G::BFULL; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + kt * 64),
-                                             (__attribute__((address_space(3))) void*)(st + G::AOPER + dma_off + i * G::NT * 16), 16, 0, 0);
-        if (G::BREM > 0 && lane < G::BREM)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[G::BFULL] + kt * 64),
-                                             (__attribute__((address_space(3))) void*)(st + dma_off_x), 16, 0, 0);
-    };
-
-    f32x4 acc[MF][NF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = p.K >> 6;
-    const int frow = lane & 15, fk = lane >> 4;
-    // fragment i of the A tile: rows wm*16*MF + 16 i + frow (row & 7 == frow & 7), k chunk ss*4 + fk -> slot (ss*4 + fk) ^ (frow & 7)
-    const int sw0 = ((fk ^ (frow & 7)) << 4);                               // sub-step 0; sub-step 1 is sw0 ^ 64
-    const int a_off = (wm * 16 * MF + frow) * 128;                          // + i * 2048
-    const int b_off = G::AOPER + (wn * 16 * NF + frow) * 128;               // + j * 2048
-    constexpr int NSET = DB ? 2 : 1;
-    bf16x8 fa[NSET][MF], fb[NSET][NF];
-
-    auto read_frags = [&](int set, const char* st, int sw) {
-#pragma unroll
-        for (int i = 0; i < MF; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 2048 + sw);
-#pragma unroll
-        for (int j = 0; j < NF; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 2048 + sw);
-    };
-    auto mfma_all = [&](int set) {
-#pragma unroll
-        for (int i = 0; i < MF; ++i)
-#pragma unroll
-            for (int j = 0; j < NF; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
-    };
-    // wait until at most `tiles` later tiles of this wave's DMA are still in flight
-    auto wait_tiles = [&](int tiles) {
-        if (NST >= 4 && tiles >= 3) wait_vm<3 * G::NDMA>();
-        else if (NST >= 3 && tiles >= 2) wait_vm<2 * G::NDMA>();
-        else if (NST >= 2 && tiles >= 1) wait_vm<G::NDMA>();
-        else wait_vm<0>();
-    };
-
-    // prologue: tiles 0 .. NST-1 fill the ring (tile i in stage i); stage t is refilled with tile t+NST behind step t's barrier
-#pragma unroll
-    for (int i = 0; i < NST; ++i)
-        if (i < nk) issue(i, i);
-    wait_tiles(min(nk, NST) - 1);
-    __builtin_amdgcn_s_barrier();
-    if (DB) read_frags(0, smem, sw0);
-
-    int stage = 0;                                                          // stage of tile t
-    for (int t = 0; t < nk; ++t) {
-        const char* st = smem + stage * G::STAGE;
-        const int nstage = (stage + 1 == NST) ? 0 : stage + 1;
-        if (DB) {
-            // sub-step 0 multiplies from set 0 while the fragments of sub-step 1 arrive in set 1
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): set 0 complete
-            read_frags(1, st, sw0 ^ 64);
-            mfma_all(0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);                             // set 1 complete: this wave is done reading stage t
-            if (t + 1 < nk) {
-                // tile t+1 landed (this wave's pieces; the barrier covers everybody's).  Issued after it: tiles t+2 .. min(nk-1, t+NST-1)
-                wait_tiles(min(nk - 1, t + NST - 1) - (t + 1));
-                __builtin_amdgcn_s_barrier();
-                if (t + NST < nk) issue(t + NST, stage);                    // stage t is free: every wave passed the barrier
-                read_frags(0, smem + nstage * G::STAGE, sw0);
-            }
-            mfma_all(1);
-        } else {
-            __builtin_amdgcn_sched_barrier(0);
-            read_frags(0, st, sw0);
-            mfma_all(0);
-            read_frags(0, st, sw0 ^ 64);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);                             // every read of stage t by this wave has returned
-            if (t + 1 < nk) {
-                wait_tiles(min(nk - 1, t + NST - 1) - (t + 1));
-                __builtin_amdgcn_s_barrier();
-                if (t + NST < nk) issue(t + NST, stage);
-            }
-            mfma_all(0);
-        }
-        stage = nstage;
-    }
-    __syncthreads();   // every wave is done with the ring before it becomes the C staging tile
-
-    float* Cs = reinterpret_cast<float*>(smem);
-    constexpr int CH = MF / G::MFC;                                         // fragment-row chunks per wave row (1 unless MFC < MF)
-    constexpr int NPASSES = (WM / G::SP) * CH;
-    for (int pass = 0; pass < NPASSES; ++pass) {
-        const int wgrp = pass / CH, chunk = pass % CH;
-        if (wm / G::SP == wgrp) {
-            const int r0 = (wm % G::SP) * 16 * G::MFC;
-#pragma unroll
-            for (int i = 0; i < MF; ++i) {
-                if (i / G::MFC != chunk) continue;
-#pragma unroll
-                for (int j = 0; j < NF; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = r0 + (i % G::MFC) * 16 + (lane >> 4) * 4 + r;
-                        const int col = wn * 16 * NF + j * 16 + (lane & 15);
-                        Cs[row * G::PITCH + col] = acc[i][j][r];
-                    }
-            }
-        }
-        __syncthreads();
-        epilogue<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>>(p, Cs, m0 + wgrp * G::SP * 16 * MF + chunk * 16 * G::MFC, n0);
-        if (pass + 1 < NPASSES) __syncthreads();
-    }
-}
-
-template <int WM, int WN, int MF, int NF, int NST, bool DB>
-int launch_k64(const GemmParams& p, hipStream_t stream) {
-    using G = K64Geo<WM, WN, MF, NF, NST, DB>;
-    static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
-    if (!configured.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64_kernel<WM, WN, MF, NF, NST, DB>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
-            return EAVQA_E_LAUNCH;
-        configured.store(true, std::memory_order_release);
-    }
-    const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
-    const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
-    hipLaunchKernelGGL((gemm_bf16_k64_kernel<WM, WN, MF, NF, NST, DB>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
-                       tiles_m, tiles_n);
-    EAVQA_LAUNCH_CHECK();
-    return EAVQA_OK;
-}
+// (Round 2's NON-specialised BK = 64 family - every wave both issuing DMA and multiplying - measured within +-10 % of the round-1
+// kernels and was superseded by the loader / consumer specialised kernels below; round 3 removed it from the library:
+// profiles/round2_gemm_k64.md keeps its numbers.)
 
 // ================================================================ loader / consumer specialisation ===
 // Round-2 finding (k64 sweep, profiles/round2_gemm_k64.md): with every wave both issuing its share of the stage's LDS-DMA pieces
@@ -223,8 +34,10 @@ int launch_k64(const GemmParams& p, hipStream_t stream) {
 // so a K-step costs max(issue, multiply).  The stage is one image [TBM A rows | TBN B rows] x 128 B cut into pieces of 8 rows;
 // loader w moves pieces w, w + LW, ...; loaders with one piece more wait on their own count (wave-uniform branch).
 // All waves take part in the C staging / store passes of the epilogue.
-template <int WM, int WN, int MF, int NF, int NST_, int LW_> struct K64SGeo {
+template <int WM, int WN, int MF, int NF, int NST_, int LW_, bool DIRECT_ = false> struct K64SGeo {
     static constexpr int NST = NST_, LW = LW_;
+    static constexpr int NFRAG = NF;
+    static constexpr bool DIRECT = DIRECT_;                              // direct epilogue: B rows read in permuted order (gemm.hip key_b)
     static constexpr int NC = WM * WN;                                   // consumer waves
     static constexpr int NT = 64 * (NC + LW);
     static constexpr int TBM = 16 * MF * WM, TBN = 16 * NF * WN;
@@ -256,7 +69,9 @@ __device__ __forceinline__ void k64s_loader_role(const char* A, const char* B, i
     for (int i = 0; i < G::P_HI; ++i) {
         const int piece = min(lw + G::LW * i, G::PT - 1);                   // (the extra slot of a P_LO loader is never issued)
         const int row = piece * 8 + (lane >> 3), slot = lane & 7;           // row & 7 == lane >> 3
-        const int kc = (slot ^ (lane >> 3)) * 16;
+        int key = lane >> 3;                                                // A rows (and B rows with the LDS-staged epilogue): row & 7
+        if constexpr (G::DIRECT) { if (row >= G::TBM) key = key_b<G::NFRAG>(row - G::TBM); }
+        const int kc = (slot ^ key) * 16;
         src[i] = row < G::TBM ? A + (int64_t)min(m0 + row, M - 1) * lda_bytes + kc
                               : B + (int64_t)min(n0 + row - G::TBM, N - 1) * ldb_bytes + kc;
         dst[i] = piece * 1024;
@@ -330,9 +145,9 @@ __device__ __forceinline__ void k64s_store_tile(const GemmParams& p, const f32x4
     }
 }
 
-template <int WM, int WN, int MF, int NF, int NST, int LW>
+template <int WM, int WN, int MF, int NF, int NST, int LW, bool DIRECT = false>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
-    using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
+    using G = K64SGeo<WM, WN, MF, NF, NST, LW, DIRECT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     if (!shaped_tile(gx, gy, tiles_m, tiles_n, tm, tn)) return;
@@ -353,67 +168,92 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(Gem
     if (wave >= G::NC) {
         k64s_loader_role<G>(reinterpret_cast<const char*>(p.A), reinterpret_cast<const char*>(p.B), p.lda * 2, p.ldb * 2, p.M, p.N, m0, n0, nk,
                             smem, wave - G::NC, lane);
+        if (DIRECT) return;                                                 // the consumers store their own accumulators
     } else {
         // ------------------------------------------------------------------ consumer
         const int frow = lane & 15, fk = lane >> 4;
         const int sw0 = ((fk ^ (frow & 7)) << 4);
         const int a_off = (wm * 16 * MF + frow) * 128;
         const int b_off = G::AOPER + (wn * 16 * NF + frow) * 128;
+        // DIRECT: fragment j of B reads the permuted tile row perm_b_row(frow, j); its swizzle key depends on j's parity only
+        // (NF = 4: rows 16 q + 4 j + r -> key (4 (j & 1) + r) ^ 4 (q >> 1); NF = 5: rows 20 q + 4 j + r -> key 4 ((q + j) & 1) + r)
+        int b_dir[2] = {0, 0};
+        if constexpr (DIRECT) {
+#pragma unroll
+            for (int par = 0; par < 2; ++par) {
+                const int row = wn * 16 * NF + perm_b_row<NF>(frow, par);       // representative of fragments j == par (mod 2)
+                b_dir[par] = G::AOPER + row * 128 + ((fk ^ key_b<NF>(row)) << 4) - par * 512;   // + 512 j below
+            }
+        }
         bf16x8 fa[2][MF], fb[2][NF];
-        auto read_frags = [&](int set, const char* st, int sw) {
+        auto read_frags = [&](int set, const char* st, int sw, int flip) {
 #pragma unroll
             for (int i = 0; i < MF; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 2048 + sw);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 2048 + sw);
+            for (int j = 0; j < NF; ++j) {
+                if constexpr (DIRECT) fb[set][j] = *reinterpret_cast<const bf16x8*>(st + ((b_dir[j & 1] + j * 512) ^ flip));
+                else fb[set][j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 2048 + sw);
+            }
         };
         auto mfma_all = [&](int set) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NF; ++j) {
+                    if constexpr (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
+                }
         };
         __builtin_amdgcn_s_barrier();
-        read_frags(0, smem, sw0);
+        read_frags(0, smem, sw0, 0);
         int stage = 0;
         for (int t = 0; t < nk; ++t) {
             const char* st = smem + stage * G::STAGE;
             const int nstage = (stage + 1 == NST) ? 0 : stage + 1;
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): set 0 complete
-            read_frags(1, st, sw0 ^ 64);
+            read_frags(1, st, sw0 ^ 64, 64);
             mfma_all(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);                             // set 1 complete: done reading stage t
             if (t + 1 < nk) {
                 __builtin_amdgcn_s_barrier();
-                read_frags(0, smem + nstage * G::STAGE, sw0);
+                read_frags(0, smem + nstage * G::STAGE, sw0, 0);
             }
             mfma_all(1);
             stage = nstage;
         }
     }
-    __syncthreads();   // ring free (every DMA was waited for by its loader before the last K-step's barrier)
-    if (p.ablate & 1) {                                                     // keep the accumulators alive without the C pass
-        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[0][0][0];
-        return;
+    if constexpr (DIRECT) {
+        // no barrier: every DMA was waited for by its loader before the last K-step's barrier, and nothing is staged through the ring
+        if (p.ablate & 1) {
+            if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[0][0][0];
+            return;
+        }
+        direct_epilogue<bf16_t, MF, NF>(p, acc, m0 + wm * 16 * MF, n0 + wn * 16 * NF, lane);
+    } else {
+        __syncthreads();   // ring free (every DMA was waited for by its loader before the last K-step's barrier)
+        if (p.ablate & 1) {                                                     // keep the accumulators alive without the C pass
+            if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[0][0][0];
+            return;
+        }
+        k64s_store_tile<G, WM, WN, MF, NF>(p, acc, smem, wave, lane, m0, n0);
     }
-    k64s_store_tile<G, WM, WN, MF, NF>(p, acc, smem, wave, lane, m0, n0);
 }
 
-template <int WM, int WN, int MF, int NF, int NST, int LW>
+template <int WM, int WN, int MF, int NF, int NST, int LW, bool DIRECT = false>
 int launch_k64s(const GemmParams& p, hipStream_t stream) {
-    using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
+    using G = K64SGeo<WM, WN, MF, NF, NST, LW, DIRECT>;
     static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
     if (!configured.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, DIRECT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
             return EAVQA_E_LAUNCH;
         configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
-    hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
+    hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, DIRECT>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
                        tiles_m, tiles_n);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
@@ -422,32 +262,28 @@ int launch_k64s(const GemmParams& p, hipStream_t stream) {
 // `rate`: ns per 128-byte operand row and K-step (64) of the fullest CU (calibrated on MI355X with tools/gemm_bench.py).
 struct K64Choice { int bm, bn, wg_per_cu; float rate; int (*launch)(const GemmParams&, hipStream_t); };
 const K64Choice K64_SHAPES[] = {
-    {128, 128, 2, 1.55f, launch_k64<2, 2, 4, 4, 2, true>},
-    {128, 80, 2, 1.55f, launch_k64<4, 1, 2, 5, 3, true>},
-    {128, 96, 1, 1.55f, launch_k64<4, 1, 2, 6, 3, true>},
-    {256, 128, 1, 1.55f, launch_k64<4, 2, 4, 4, 3, true>},
-    {256, 160, 1, 1.55f, launch_k64<4, 2, 4, 5, 3, true>},
-    {256, 192, 1, 1.60f, launch_k64<4, 2, 4, 6, 2, true>},
-    {256, 256, 1, 1.60f, launch_k64<2, 4, 8, 4, 2, false>},
-    {256, 256, 1, 1.60f, launch_k64<2, 4, 8, 4, 2, true>},      // experiment: second fragment set (register pressure)
-    {128, 128, 1, 1.55f, launch_k64<2, 2, 4, 4, 3, true>},      // experiment: deeper ring, one workgroup per CU
-    // loader / consumer specialised (ids 11..)
-    {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 2>},          // 11
-    {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 4>},          // 12
-    {128, 128, 2, 1.1f, launch_k64s<2, 2, 4, 4, 2, 4>},         // 13
-    {256, 128, 1, 1.97f, launch_k64s<4, 2, 4, 4, 3, 4>},        // 14
-    {256, 160, 1, 1.93f, launch_k64s<4, 2, 4, 5, 3, 4>},        // 15
-    {128, 80, 1, 1.56f, launch_k64s<4, 1, 2, 5, 4, 2>},         // 16: four stages (one workgroup per CU)
-    {128, 96, 1, 1.1f, launch_k64s<4, 1, 2, 6, 3, 2>},          // 17
-    {256, 192, 1, 1.1f, launch_k64s<4, 2, 4, 6, 2, 4>},         // 18
-    {256, 256, 1, 1.1f, launch_k64s<2, 4, 8, 4, 2, 4>},         // 19
-    {128, 128, 1, 1.73f, launch_k64s<2, 2, 4, 4, 3, 2>},        // 20: three stages
-    {256, 128, 1, 1.1f, launch_k64s<2, 2, 8, 4, 3, 4>},         // 21: four fat consumer waves (128 x 64 each)
-    {128, 256, 1, 1.97f, launch_k64s<2, 4, 4, 4, 3, 4>},        // 22
+    // loader / consumer specialised, LDS-staged epilogue (knob ids 2..)
+    {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 2>},          //  2
+    {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 4>},          //  3
+    {128, 128, 2, 1.1f, launch_k64s<2, 2, 4, 4, 2, 4>},         //  4
+    {256, 128, 1, 1.97f, launch_k64s<4, 2, 4, 4, 3, 4>},        //  5
+    {256, 160, 1, 1.93f, launch_k64s<4, 2, 4, 5, 3, 4>},        //  6
+    {128, 80, 1, 1.56f, launch_k64s<4, 1, 2, 5, 4, 2>},         //  7: four stages (one workgroup per CU)
+    {128, 96, 1, 1.1f, launch_k64s<4, 1, 2, 6, 3, 2>},          //  8
+    {256, 192, 1, 1.1f, launch_k64s<4, 2, 4, 6, 2, 4>},         //  9
+    {256, 256, 1, 1.1f, launch_k64s<2, 4, 8, 4, 2, 4>},         // 10
+    {128, 128, 1, 1.73f, launch_k64s<2, 2, 4, 4, 3, 2>},        // 11: three stages
+    {128, 256, 1, 1.97f, launch_k64s<2, 4, 4, 4, 3, 4>},        // 12
+    // direct epilogue (accumulators -> global without the LDS staging pass; gemm.hip direct_epilogue): what the dispatcher ranks
+    {128, 80, 1, 1.56f, launch_k64s<4, 1, 2, 5, 4, 2, true>},   // 13 = 7 direct
+    {256, 128, 1, 1.97f, launch_k64s<4, 2, 4, 4, 3, 4, true>},  // 14 = 5 direct
+    {256, 160, 1, 1.93f, launch_k64s<4, 2, 4, 5, 3, 4, true>},  // 15 = 6 direct
+    {128, 128, 1, 1.73f, launch_k64s<2, 2, 4, 4, 3, 2, true>},  // 16 = 11 direct
+    {128, 256, 1, 1.97f, launch_k64s<2, 4, 4, 4, 3, 4, true>},  // 17 = 12 direct
 };
 constexpr int N_K64 = sizeof(K64_SHAPES) / sizeof(K64_SHAPES[0]);
-// the tiles the dispatcher chooses among (indices into K64_SHAPES): s128x80 (4 stages), s256x128, s256x160, s128x128 (3 stages), s128x256
-constexpr int K64_AUTO[] = {14, 12, 13, 18, 20};
+// the tiles the dispatcher chooses among (indices into K64_SHAPES): 128x80 (4 stages), 256x128, 256x160, 128x128 (3 stages), 128x256
+constexpr int K64_AUTO[] = {11, 12, 13, 14, 15};      // table indices of the direct-epilogue builds (knob ids 13..17)
 constexpr int N_K64_AUTO = sizeof(K64_AUTO) / sizeof(K64_AUTO[0]);
 
 

@@ -182,9 +182,9 @@ def test_gemm_large_bf16_statistical(ops, gemm_path):
     assert rel < 1e-5, rel   # products exact in fp32, only summation order differs
 
 
-K64_NAMES = ["128x128", "128x80", "128x96", "256x128", "256x160", "256x192", "256x256", "256x256db", "128x128s3",
-             "s128x80l2", "s128x80l4", "s128x128l4", "s256x128l4", "s256x160l4", "s128x80n4", "s128x96", "s256x192", "s256x256", "s128x128n3",
-             "s256x128fat", "s128x256"]      # s*: loader / consumer specialised
+K64_NAMES = ["s128x80l2", "s128x80l4", "s128x128l4", "s256x128l4", "s256x160l4", "s128x80n4", "s128x96", "s256x192", "s256x256", "s128x128n3",
+             "s128x256",                                                                  # loader / consumer specialised, LDS-staged epilogue
+             "d128x80", "d256x128", "d256x160", "d128x128", "d128x256"]                   # ... with the direct (register -> global) epilogue
 
 
 @pytest.mark.parametrize("shape_id", range(len(K64_NAMES)), ids=K64_NAMES)
@@ -203,9 +203,20 @@ def test_gemm_full_line_family(ops, shape_id, M, N, K):
         aux = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
         out2 = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act="gelu_new", aux_out=aux, residual=res.to(DEV), out_f32=True, alpha=0.25)
         out3 = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), act="relu")
+        # activation backward at aux_in (the dgrad of an FFN-up) and a half residual stream written in place
+        u = rnd(M, N, dtype=torch.bfloat16, seed=25)
+        out4 = ops.gemm(a.to(DEV), b.to(DEV), act="quick_gelu", aux_in=u.to(DEV))
+        stream = rnd(M, N, seed=26).to(torch.float16).to(DEV)
+        want5 = ref + bias + stream.float().cpu()
+        out5 = ops.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=stream, out=stream)
         torch.cuda.synchronize()
     finally:
         ops.KernelSelect.gemm = 0
+    uf = u.float()
+    sg = torch.sigmoid(1.702 * uf)
+    want4 = ref * (sg * (1 + 1.702 * uf * (1 - sg)))
+    assert (out4.float().cpu() - want4).abs().max().item() <= 1.5e-2 * max(1.0, want4.abs().max().item())
+    assert out5.dtype == torch.float16 and (out5.float().cpu() - want5).abs().max().item() <= 2e-3 * max(1.0, want5.abs().max().item()) + 1e-3 * math.sqrt(K)
     assert (out.cpu() - ref).abs().max().item() <= 1e-3 * math.sqrt(K)
     pre = ref * 0.25 + bias
     assert (aux.float().cpu() - pre).abs().max().item() <= 2e-2 * max(1.0, pre.abs().max().item())
@@ -220,7 +231,7 @@ def test_gemm_full_line_family_is_the_default_dispatch(ops):
     a, b = rnd(1943, 1280, dtype=torch.bfloat16, seed=31).to(DEV), rnd(1280, 1280, dtype=torch.bfloat16, seed=32).to(DEV)
     auto = ops.gemm(a, b, out_f32=True)
     same = []
-    for i in range(7):
+    for i in range(len(K64_NAMES)):
         ops.KernelSelect.gemm = (2 + i) << 8
         same.append(bool(torch.equal(auto, ops.gemm(a, b, out_f32=True))))
     ops.KernelSelect.gemm = 0

@@ -44,14 +44,18 @@ def main():
     ap.add_argument("--ablate", type=int, default=0, help="timing-only ablation variant of the fast kernel (wrong results)")
     ap.add_argument("--big", type=int, default=0, help="0 auto, 1 never 256x256, 2 always 256x256")
     ap.add_argument("--shape", type=int, default=0, help="0 auto, 1 never a shaped tile, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192")
-    ap.add_argument("--k64", type=int, default=0, help="full-line family: 0 by cost model, 1 never (round-1 kernels), 2.. force K64_SHAPES[id - 2]")
+    ap.add_argument("--k64", type=int, default=0, help="full-line family: 0 by cost model, 1 never (round-1 kernels), 2.. force K64_SHAPES[id - 2] "
+                                                        "(2..12 LDS-staged epilogue, 13..17 direct epilogue: csrc/gemm_k64.hip)")
+    ap.add_argument("--epi-lds", action="store_true", help="256 x 256 kernel: the LDS-staged epilogue build instead of the direct one")
+    ap.add_argument("--epi", default="", help="epilogue of the timed call: '' plain bf16 out | 'fc1' bias + gelu_new + aux_out | 'quick' bias + quick_gelu | "
+                                              "'res32' bias + fp32 residual in place | 'res16' bias + half residual in place | 'bwd' gelu_new derivative at aux_in")
     ap.add_argument("--deep", type=int, default=0, help="8-stage ring: 0 auto, 1 never, 2 always")
     ap.add_argument("--check", action="store_true", help="compare the result with a torch matmul")
     ap.add_argument("--cold", action="store_true", help="rotate over enough copies of the weight to defeat L2 + Infinity Cache")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
     ops.KernelSelect.gemm = (args.stagger | (args.ablate << 4) | (int(args.general) << 7) | (args.k64 << 8) | (args.big << 14) | (args.deep << 16)
-                             | (args.shape << 18))
+                             | (args.shape << 18) | (int(args.epi_lds) << 21))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
     for M, N, K, what in SHAPES:
@@ -64,8 +68,15 @@ def main():
         if args.cold:
             bs = [b.clone() for _ in range(max(2, int(6e8 / (2.0 * N * K)) + 1))]
         kw = {}
-        if args.epilogue:
+        if args.epilogue or args.epi == "fc1":
             kw = dict(bias=torch.zeros(N, device=dev), act="gelu_new", aux_out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        elif args.epi == "quick":
+            kw = dict(bias=torch.zeros(N, device=dev), act="quick_gelu")
+        elif args.epi == "bwd":
+            kw = dict(act="gelu_new", aux_in=torch.randn(M, N, device=dev).to(torch.bfloat16))
+        elif args.epi in ("res32", "res16"):
+            out = torch.zeros(M, N, device=dev, dtype=torch.float32 if args.epi == "res32" else torch.float16)
+            kw = dict(bias=torch.zeros(N, device=dev), residual=out)
         for _ in range(3):
             ops.gemm(a, b, out=out, **kw)
         if args.check and not kw:
