@@ -67,11 +67,15 @@ template <> struct elem<f16_t> {
 // tanh through one v_exp + one v_rcp: tanh(x) = 1 - 2 / (exp(2x) + 1).  |error| <= ~2e-7 absolute (exp2-based
 // __expf is within 2 ulp, the form is stable at both tails: exp -> inf gives 1, exp -> 0 gives -1).  The libm
 // tanhf costs ~10x more VALU time, which showed up as +60 % on the gelu_new GEMM epilogues.
+// The reciprocal is v_rcp_f32 (1 ulp) through the builtin: `__fdividef` is a plain `/` on this toolchain and compiles to the IEEE
+// division sequence (v_div_scale x2, v_rcp, four FMAs, v_div_fmas, v_div_fixup: ~12 VALU instructions per element) - round 3 found
+// it made the QuickGELU epilogue of the CLIP tower's FFN-up cost +35 % of the whole GEMM (168 M sigmoid evaluations per launch).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_tanh(float x) {
     const float e = __expf(2.f * x);
-    return 1.f - __fdividef(2.f, e + 1.f);
+    return 1.f - 2.f * fast_rcp(e + 1.f);
 }
-__device__ __forceinline__ float fast_sigmoid(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+__device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.f + __expf(-x)); }
 
 __device__ __forceinline__ float act_fwd(int act, float x) {
     switch (act) {

@@ -28,9 +28,8 @@ struct Knobs {
     int big_mode;       // [15:14] round-1 256 x 256 kernel: 0 by shape, 1 never, 2 always (K % 64 == 0)
     int deep;           // [17:16] 2 = force the 8-stage ring of the round-1 128 x 128 kernel (experiment)
     int shape_mode;     // [20:18] round-1 shaped tiles: 0 by cost model, 1 never, 2.. force SHAPES[id - 2]
-    bool epi_lds;       // [21]    256 x 256 kernel: the LDS-staged epilogue build instead of the direct one (A / B, parity)
     explicit Knobs(int k = 0) : stagger(k & 15), ablate((k >> 4) & 7), disable_fast(((k >> 7) & 1) != 0), k64_mode((k >> 8) & 63),
-                                big_mode((k >> 14) & 3), deep((k >> 16) & 3), shape_mode((k >> 18) & 7), epi_lds(((k >> 21) & 1) != 0) {}
+                                big_mode((k >> 14) & 3), deep((k >> 16) & 3), shape_mode((k >> 18) & 7) {}
 };
 
 struct GemmParams {
@@ -210,163 +209,9 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, const float* Cs, i
     }
 }
 
-// ---- direct epilogue: accumulators -> global memory WITHOUT the LDS staging pass (the C pass through LDS cost
-// 1.9-4.8 us of every launch).  The consumer waves multiply with the operands SWAPPED, acc = mfma(B fragment, A fragment): the
-// 16 x 16 result then has its four registers along n and its lane column along m.  With the B fragment rows permuted - lane row
-// 4 q + r of fragment j reads row 4 NF q + 4 j + r of the wave's 16 NF tile columns - lane group g = lane >> 4 owns the 4 NF
-// CONSECUTIVE columns g 4NF .. (g + 1) 4NF - 1 of row (lane & 15) of each of its MF 16-row fragments: bias, activation, aux, residual
-// and the C store are row-contiguous straight from registers (a wave's store instructions of one fragment row cover 16 rows x
-// 16 NF columns: whole 128-byte lines at NF = 4).  LDS bank conflicts of the permuted ds_read_b128 fragment reads: none with the
-// B-rows key below (brute-forced over the instruction's four 16-lane groups, tools/lds_bank_check.py).
-// Swizzle key of B-tile row r (the 16-byte chunk kc of the row sits at slot kc ^ key): NF = 4 needs bit 2 flipped for rows 32..63 of
-// every 64 (lanes q = 0 / 3 and q = 1 / 2 of a group would otherwise meet on one slot); NF = 5 keeps r & 7.
-template <int NF> __device__ __forceinline__ int key_b(int row) {
-    static_assert(NF == 4 || NF == 5, "direct epilogue: B-row permutation proven conflict-free for NF = 4 and 5 only");
-    return NF == 4 ? ((row & 7) ^ (((row >> 5) & 1) << 2)) : (row & 7);
-}
-// tile row (within the wave's 16 NF columns) read by lane row `fr` of fragment j
-template <int NF> __device__ __forceinline__ int perm_b_row(int fr, int j) { return (fr >> 2) * 4 * NF + 4 * j + (fr & 3); }
-
-// The body is written in three passes over the wave's accumulators IN PLACE, so that only the middle pass - pure register arithmetic - is
-// repeated per activation (one copy of the loads / stores per kernel instead of one per activation x mode: compile time).
-template <typename T> __device__ __forceinline__ void quad_store_aux(const GemmParams& p, int m, int n, const f32x4& v, bool vec) {
-    T* q = reinterpret_cast<T*>(p.aux_out) + (int64_t)m * p.ld_aux + n;
-    if (vec) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
-    else
-        for (int j = 0; j < 4; ++j)
-            if (n + j < p.N) elem<T>::st(q + j, v[j]);
-}
-template <typename T> __device__ __forceinline__ float4 quad_load_aux(const GemmParams& p, int m, int n, bool vec) {
-    const T* q = reinterpret_cast<const T*>(p.aux_in) + (int64_t)m * p.ld_aux + n;
-    if (vec) return elem<T>::ld4(q);
-    float u[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < 4; ++j)
-        if (n + j < p.N) u[j] = elem<T>::ld(q + j);
-    return make_float4(u[0], u[1], u[2], u[3]);
-}
-// residual add + C store of one row's four columns
-template <typename T, bool FULL> __device__ __forceinline__ void quad_finish(const GemmParams& p, int m, int n, f32x4 v) {
-    const bool full = FULL || (n + 3 < p.N);
-    if (p.residual) {
-        float4 t;
-        const bool vec = FULL || (full && p.vec_res);
-        if (p.res_lowp == 2) {
-            const f16_t* q = reinterpret_cast<const f16_t*>(p.residual) + (int64_t)m * p.ldr + n;
-            if (vec) t = elem<f16_t>::ld4(q);
-            else { float u[4] = {0.f, 0.f, 0.f, 0.f}; for (int j = 0; j < 4; ++j) if (n + j < p.N) u[j] = elem<f16_t>::ld(q + j); t = make_float4(u[0], u[1], u[2], u[3]); }
-        } else if (p.res_lowp) {
-            const T* q = reinterpret_cast<const T*>(p.residual) + (int64_t)m * p.ldr + n;
-            if (vec) t = elem<T>::ld4(q);
-            else { float u[4] = {0.f, 0.f, 0.f, 0.f}; for (int j = 0; j < 4; ++j) if (n + j < p.N) u[j] = elem<T>::ld(q + j); t = make_float4(u[0], u[1], u[2], u[3]); }
-        } else {
-            const float* q = reinterpret_cast<const float*>(p.residual) + (int64_t)m * p.ldr + n;
-            if (vec) t = *reinterpret_cast<const float4*>(q);
-            else { float u[4] = {0.f, 0.f, 0.f, 0.f}; for (int j = 0; j < 4; ++j) if (n + j < p.N) u[j] = q[j]; t = make_float4(u[0], u[1], u[2], u[3]); }
-        }
-        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-    }
-    const bool vec = FULL || (full && p.vec_c);
-    if (p.out_f32) {
-        float* q = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
-        if (vec) *reinterpret_cast<float4*>(q) = make_float4(v[0], v[1], v[2], v[3]);
-        else for (int j = 0; j < 4; ++j) if (n + j < p.N) q[j] = v[j];
-    } else if (p.out_f16) {
-        f16_t* q = reinterpret_cast<f16_t*>(p.C) + (int64_t)m * p.ldc + n;
-        if (vec) elem<f16_t>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
-        else for (int j = 0; j < 4; ++j) if (n + j < p.N) elem<f16_t>::st(q + j, v[j]);
-    } else {
-        T* q = reinterpret_cast<T*>(p.C) + (int64_t)m * p.ldc + n;
-        if (vec) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
-        else for (int j = 0; j < 4; ++j) if (n + j < p.N) elem<T>::st(q + j, v[j]);
-    }
-}
-
-template <int ACT, int MF, int NF> __device__ __forceinline__ void act_all(f32x4 (&acc)[MF][NF]) {
-#pragma unroll
-    for (int i = 0; i < MF; ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = act_fwd(ACT, acc[i][j][r]);
-}
-template <typename T, int ACT, bool FULL, int MF, int NF>
-__device__ __forceinline__ void act_bwd_all(const GemmParams& p, f32x4 (&acc)[MF][NF], int m_base, int n0, int l15) {
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int m = m_base + 16 * i + l15;
-        if (!FULL && m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int n = n0 + 4 * j;
-            if (!FULL && n >= p.N) continue;
-            const float4 u = quad_load_aux<T>(p, m, n, FULL || (n + 3 < p.N && p.vec_aux));
-            acc[i][j][0] *= act_bwd(ACT, u.x); acc[i][j][1] *= act_bwd(ACT, u.y); acc[i][j][2] *= act_bwd(ACT, u.z); acc[i][j][3] *= act_bwd(ACT, u.w);
-        }
-    }
-}
-
-template <typename T, bool FULL, int MF, int NF>
-__device__ __forceinline__ void direct_body(const GemmParams& p, f32x4 (&acc)[MF][NF], int m_base, int n_base, int lane) {
-    const int l15 = lane & 15, n0 = n_base + (lane >> 4) * 4 * NF;
-    // pass 1: v = alpha * acc + bias (in place), pre-activation out
-    {
-        float bias4[NF][4];
-#pragma unroll
-        for (int j = 0; j < NF; ++j) load_bias4<FULL>(p, n0 + 4 * j, bias4[j]);
-#pragma unroll
-        for (int i = 0; i < MF; ++i) {
-            const int m = m_base + 16 * i + l15;
-            const bool row_ok = FULL || m < p.M;
-            const float al = (p.row_scale && row_ok) ? p.alpha * p.row_scale[m] : p.alpha;
-#pragma unroll
-            for (int j = 0; j < NF; ++j) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = al * acc[i][j][r] + bias4[j][r];
-                const int n = n0 + 4 * j;
-                if (p.aux_out && row_ok && (FULL || n < p.N)) quad_store_aux<T>(p, m, n, acc[i][j], FULL || (n + 3 < p.N && p.vec_aux));
-            }
-        }
-    }
-    // pass 2: activation (forward), or its derivative at aux_in (backward) - the only part written once per activation
-    if (p.aux_in) {
-        switch (p.act) {
-            case EAVQA_ACT_TANH: act_bwd_all<T, EAVQA_ACT_TANH, FULL, MF, NF>(p, acc, m_base, n0, l15); break;
-            case EAVQA_ACT_RELU: act_bwd_all<T, EAVQA_ACT_RELU, FULL, MF, NF>(p, acc, m_base, n0, l15); break;
-            case EAVQA_ACT_GELU_NEW: act_bwd_all<T, EAVQA_ACT_GELU_NEW, FULL, MF, NF>(p, acc, m_base, n0, l15); break;
-            case EAVQA_ACT_QUICK_GELU: act_bwd_all<T, EAVQA_ACT_QUICK_GELU, FULL, MF, NF>(p, acc, m_base, n0, l15); break;
-            default: break;                                  // act == none: derivative 1
-        }
-    } else {
-        switch (p.act) {
-            case EAVQA_ACT_TANH: act_all<EAVQA_ACT_TANH, MF, NF>(acc); break;
-            case EAVQA_ACT_RELU: act_all<EAVQA_ACT_RELU, MF, NF>(acc); break;
-            case EAVQA_ACT_GELU_NEW: act_all<EAVQA_ACT_GELU_NEW, MF, NF>(acc); break;
-            case EAVQA_ACT_QUICK_GELU: act_all<EAVQA_ACT_QUICK_GELU, MF, NF>(acc); break;
-            default: break;
-        }
-    }
-    // pass 3: residual, C
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        const int m = m_base + 16 * i + l15;
-        if (!FULL && m >= p.M) continue;
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            const int n = n0 + 4 * j;
-            if (!FULL && n >= p.N) continue;
-            quad_finish<T, FULL>(p, m, n, acc[i][j]);
-        }
-    }
-}
-
-// (m_base, n_base): first row / column of the WAVE's 16 MF x 16 NF block of C
-template <typename T, int MF, int NF>
-__device__ __forceinline__ void direct_epilogue(const GemmParams& p, f32x4 (&acc)[MF][NF], int m_base, int n_base, int lane) {
-    const bool full = (m_base + 16 * MF <= p.M) && (n_base + 16 * NF <= p.N) && p.vec_c && (!(p.aux_in || p.aux_out) || p.vec_aux) &&
-                      (!p.residual || p.vec_res) && (!p.bias || p.vec_bias);
-    if (full) direct_body<T, true, MF, NF>(p, acc, m_base, n_base, lane);
-    else direct_body<T, false, MF, NF>(p, acc, m_base, n_base, lane);
-}
+// (Round 3 built a direct register -> global epilogue for the specialised tiles - operands swapped, B fragment rows permuted so that a
+// lane owns 16 consecutive columns - and measured it 10-70 % SLOWER than the LDS-staged pass below (a wave's store covers 16 rows x
+// 32 bytes: partial lines); removed again, numbers in profiles/round3_direct_epilogue.md.)
 
 // =============================================================== bf16 ===
 constexpr int BK16 = 64;                          // k per LDS tile (bf16)
@@ -984,7 +829,6 @@ __device__ __forceinline__ bool big_tile(const GemmParams& p, int gx, int gy, in
     return true;
 }
 
-template <bool DIRECT>
 __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
@@ -1004,7 +848,7 @@ __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int g
         const int c = tid + 1024 * i;
         const int row = c >> 3, pc = c & 7;
         asrc[i] = A + (int64_t)min(m0 + row, p.M - 1) * p.lda + (pc ^ (row & 7)) * 8;
-        bsrc[i] = B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + (pc ^ (DIRECT ? key_b<4>(row) : (row & 7))) * 8;
+        bsrc[i] = B + (int64_t)min(n0 + row, p.N - 1) * p.ldb + (pc ^ (row & 7)) * 8;
     }
     const int dma_off = wave * 1024;
     auto issue = [&](int kt) {
@@ -1027,15 +871,6 @@ __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int g
     const int nk = p.K / GBK;
     const int frow = lane & 15, fk = lane >> 4;
     const int arow = wm * 64 + frow, brow = wn * 64 + frow;     // + 16 i ; row & 7 == frow & 7 for every fragment
-    // DIRECT (direct_epilogue above): fragment j of B reads the permuted tile row 16 q + 4 j + r (lane row 4 q + r); key by j's parity
-    int b_dir[2] = {0, 0};
-    if (DIRECT) {
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int row = wn * 64 + perm_b_row<4>(frow, par);
-            b_dir[par] = GOPER + row * 128 + ((fk ^ key_b<4>(row)) << 4) - par * 512;
-        }
-    }
     issue(0);
     for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_sched_barrier(0);
@@ -1050,22 +885,13 @@ __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int g
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(st + (arow + 16 * i) * 128 + sw);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (DIRECT) bfr[j] = *reinterpret_cast<const bf16x8*>(st + ((b_dir[j & 1] + j * 512) ^ (s << 6)));
-                else bfr[j] = *reinterpret_cast<const bf16x8*>(st + GOPER + (brow + 16 * j) * 128 + sw);
-            }
+            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(st + GOPER + (brow + 16 * j) * 128 + sw);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-    }
-    if (DIRECT) {
-        direct_epilogue<bf16_t, 4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
-        return;
     }
     __syncthreads();
 
@@ -1089,11 +915,10 @@ __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int g
     }
 }
 
-template <bool DIRECT>
-int launch_big_impl(const GemmParams& p, hipStream_t stream) {
+int launch_big(const GemmParams& p, hipStream_t stream) {
     static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
     if (!configured.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<DIRECT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 GLDS_BYTES) != hipSuccess)
             return EAVQA_E_LAUNCH;
         configured.store(true, std::memory_order_release);
@@ -1108,14 +933,9 @@ int launch_big_impl(const GemmParams& p, hipStream_t stream) {
     }
     const int gx = best_gx, gy = 8 / gx;
     const int per_xcd = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
-    hipLaunchKernelGGL(gemm_bf16_big_kernel<DIRECT>, dim3(per_xcd * 8), dim3(1024), GLDS_BYTES, stream, p, gx, gy, tiles_m, tiles_n);
+    hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3(per_xcd * 8), dim3(1024), GLDS_BYTES, stream, p, gx, gy, tiles_m, tiles_n);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
-}
-
-// epi_lds (eavqa_gemm_ex knob bit 21): the LDS-staged epilogue build (A / B measurements, parity of both builds)
-int launch_big(const GemmParams& p, hipStream_t stream, bool epi_lds = false) {
-    return epi_lds ? launch_big_impl<false>(p, stream) : launch_big_impl<true>(p, stream);
 }
 
 bool use_big(const GemmParams& p, const Knobs& kn) {
@@ -1447,13 +1267,13 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
             // the same multi-round charge (3 rounds on the prefill QKV shape: 215 us measured against 190 modelled)
             const float big_loop = float(big_rounds) * 2.99f * 512.f * (K / 64);
             const float big_cost = big_loop * (big_rounds > 1 ? 1.35f : 1.f) + 6000.f;
-            if (M > 64 && big_cost < best) return launch_big(p, s, kn.epi_lds);
+            if (M > 64 && big_cost < best) return launch_big(p, s);
             return K64_SHAPES[pick].launch(p, s);
         }
         if (a_kc && b_kc && !kn.disable_fast && (K % FBK) == 0) {
             if (kn.shape_mode >= 2 && kn.shape_mode < 7) return SHAPES[kn.shape_mode - 2].launch(p, s);
             const bool big_ok = (K % GBK) == 0 && kn.big_mode != 1;
-            if (big_ok && kn.big_mode == 2) return launch_big(p, s, kn.epi_lds);
+            if (big_ok && kn.big_mode == 2) return launch_big(p, s);
             // candidates in order of preference at equal cost: 128 x 128 (two workgroups per CU), 256 x 256, shaped tiles
             float best = tile_cost(p, 128, 128, RATE_FAST);
             int pick = -1;                                   // -1 fast, -2 big, >= 0 SHAPES[pick]
@@ -1464,7 +1284,7 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                     if (c < best * 0.95f) { best = c; pick = i; }
                 }
             if (pick >= 0) return SHAPES[pick].launch(p, s);
-            if (pick == -2) return launch_big(p, s, kn.epi_lds);
+            if (pick == -2) return launch_big(p, s);
             return launch_fast(p, s, kn);
         }
         if (a_kc && b_kc) return launch(gemm_bf16_kernel<true, true>, p, s);
@@ -1546,7 +1366,7 @@ extern "C" int eavqa_gemm_fp8(int M, int N, int K, const void* A, int64_t lda, c
     q.K = K / 2;                                  // k64_cost counts 64-element (128-byte) steps of bf16
     int pick = 0;
     float best = k64_cost(q, FP8_SHAPES[0]);
-    for (int i = 1; i < N_FP8_AUTO; ++i) {
+    for (int i = 1; i < N_FP8; ++i) {
         const float c = k64_cost(q, FP8_SHAPES[i]);
         if (c < best) { best = c; pick = i; }
     }

@@ -16,9 +16,9 @@
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
-template <int WM, int WN, int MF, int NF, int NST, int LW, bool DB, bool DIRECT = true>
+template <int WM, int WN, int MF, int NF, int NST, int LW, bool DB>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_fp8_k128s_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
-    using G = K64SGeo<WM, WN, MF, NF, NST, LW, DIRECT>;
+    using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     if (!shaped_tile(gx, gy, tiles_m, tiles_n, tm, tn)) return;
@@ -36,21 +36,11 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_fp8_k128s_kernel(Gem
     if (wave >= G::NC) {
         k64s_loader_role<G>(reinterpret_cast<const char*>(p.A), reinterpret_cast<const char*>(p.B), p.lda, p.ldb, p.M, p.N, m0, n0, nk, smem,
                             wave - G::NC, lane);
-        if (DIRECT) return;                                                 // the consumers store their own accumulators
     } else {
         const int frow = lane & 15, fk = lane >> 4;
         const int sw0 = ((fk ^ (frow & 7)) << 4);                           // chunk g; chunk g + 4 is sw0 ^ 64
         const int a_off = (wm * 16 * MF + frow) * 128;
         const int b_off = G::AOPER + (wn * 16 * NF + frow) * 128;
-        // DIRECT (gemm.hip direct_epilogue): B fragment rows permuted, operands swapped - as in gemm_bf16_k64s_kernel
-        int b_dir[2] = {0, 0};
-        if constexpr (DIRECT) {
-#pragma unroll
-            for (int par = 0; par < 2; ++par) {
-                const int row = wn * 16 * NF + perm_b_row<NF>(frow, par);
-                b_dir[par] = G::AOPER + row * 128 + ((fk ^ key_b<NF>(row)) << 4) - par * 512;
-            }
-        }
         constexpr int NSET = DB ? 2 : 1;
         i32x8 fa[NSET][MF], fb[NSET][NF];
         auto read_frags = [&](int set, const char* st) {
@@ -62,9 +52,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_fp8_k128s_kernel(Gem
             }
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
-                const int o = DIRECT ? b_dir[j & 1] + j * 512 : b_off + j * 2048 + sw0;
-                const i32x4 lo = *reinterpret_cast<const i32x4*>(st + o);
-                const i32x4 hi = *reinterpret_cast<const i32x4*>(st + (o ^ 64));
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(st + b_off + j * 2048 + sw0);
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(st + b_off + j * 2048 + (sw0 ^ 64));
                 fb[set][j] = (i32x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
         };
@@ -72,12 +61,8 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_fp8_k128s_kernel(Gem
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) {    // cbsz = blgp = 0: both operands e4m3; block scales 2^0 (E8M0 byte 127 in every lane)
-                    if constexpr (DIRECT)
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                    else
-                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                }
+                for (int j = 0; j < NF; ++j)      // cbsz = blgp = 0: both operands e4m3; block scales 2^0 (E8M0 byte 127 in every lane)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
         };
         __builtin_amdgcn_s_barrier();                                       // tile 0 landed
         int stage = 0;
@@ -105,27 +90,23 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_fp8_k128s_kernel(Gem
             }
         }
     }
-    if constexpr (DIRECT) {
-        direct_epilogue<bf16_t, MF, NF>(p, acc, m0 + wm * 16 * MF, n0 + wn * 16 * NF, lane);
-    } else {
-        __syncthreads();
-        k64s_store_tile<G, WM, WN, MF, NF>(p, acc, smem, wave, lane, m0, n0);
-    }
+    __syncthreads();
+    k64s_store_tile<G, WM, WN, MF, NF>(p, acc, smem, wave, lane, m0, n0);
 }
 
-template <int WM, int WN, int MF, int NF, int NST, int LW, bool DB, bool DIRECT = true>
+template <int WM, int WN, int MF, int NF, int NST, int LW, bool DB>
 int launch_fp8(const GemmParams& p, hipStream_t stream) {
-    using G = K64SGeo<WM, WN, MF, NF, NST, LW, DIRECT>;
+    using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
     static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
     if (!configured.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_k128s_kernel<WM, WN, MF, NF, NST, LW, DB, DIRECT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_fp8_k128s_kernel<WM, WN, MF, NF, NST, LW, DB>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
             return EAVQA_E_LAUNCH;
         configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
-    hipLaunchKernelGGL((gemm_fp8_k128s_kernel<WM, WN, MF, NF, NST, LW, DB, DIRECT>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
+    hipLaunchKernelGGL((gemm_fp8_k128s_kernel<WM, WN, MF, NF, NST, LW, DB>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
                        tiles_m, tiles_n);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
@@ -137,12 +118,8 @@ const K64Choice FP8_SHAPES[] = {
     {256, 160, 1, 1.93f, launch_fp8<4, 2, 4, 5, 3, 4, false>},
     {128, 128, 1, 1.73f, launch_fp8<2, 2, 4, 4, 3, 2, false>},
     {128, 256, 1, 1.97f, launch_fp8<2, 4, 4, 4, 3, 4, false>},
-    // the LDS-staged epilogue builds of the first two tiles (A / B, parity): `tile` 6, 7 of eavqa_gemm_fp8; never chosen by shape
-    {128, 80, 1, 1.56f, launch_fp8<4, 1, 2, 5, 4, 2, true, false>},
-    {256, 128, 1, 1.97f, launch_fp8<4, 2, 4, 4, 3, 4, false, false>},
 };
 constexpr int N_FP8 = sizeof(FP8_SHAPES) / sizeof(FP8_SHAPES[0]);
-constexpr int N_FP8_AUTO = 5;                                  // the dispatcher ranks the first five (direct epilogue)
 
 // ---- row-wise quantisation: x[r, :] (bf16 or f32) -> e4m3 bytes + scale[r] = amax(|x[r, :]|) / 448 (1 where the row is all zero)
 template <typename T>

@@ -34,10 +34,8 @@ template <int N> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_
 // so a K-step costs max(issue, multiply).  The stage is one image [TBM A rows | TBN B rows] x 128 B cut into pieces of 8 rows;
 // loader w moves pieces w, w + LW, ...; loaders with one piece more wait on their own count (wave-uniform branch).
 // All waves take part in the C staging / store passes of the epilogue.
-template <int WM, int WN, int MF, int NF, int NST_, int LW_, bool DIRECT_ = false> struct K64SGeo {
+template <int WM, int WN, int MF, int NF, int NST_, int LW_> struct K64SGeo {
     static constexpr int NST = NST_, LW = LW_;
-    static constexpr int NFRAG = NF;
-    static constexpr bool DIRECT = DIRECT_;                              // direct epilogue: B rows read in permuted order (gemm.hip key_b)
     static constexpr int NC = WM * WN;                                   // consumer waves
     static constexpr int NT = 64 * (NC + LW);
     static constexpr int TBM = 16 * MF * WM, TBN = 16 * NF * WN;
@@ -69,9 +67,7 @@ __device__ __forceinline__ void k64s_loader_role(const char* A, const char* B, i
     for (int i = 0; i < G::P_HI; ++i) {
         const int piece = min(lw + G::LW * i, G::PT - 1);                   // (the extra slot of a P_LO loader is never issued)
         const int row = piece * 8 + (lane >> 3), slot = lane & 7;           // row & 7 == lane >> 3
-        int key = lane >> 3;                                                // A rows (and B rows with the LDS-staged epilogue): row & 7
-        if constexpr (G::DIRECT) { if (row >= G::TBM) key = key_b<G::NFRAG>(row - G::TBM); }
-        const int kc = (slot ^ key) * 16;
+        const int kc = (slot ^ (lane >> 3)) * 16;
         src[i] = row < G::TBM ? A + (int64_t)min(m0 + row, M - 1) * lda_bytes + kc
                               : B + (int64_t)min(n0 + row - G::TBM, N - 1) * ldb_bytes + kc;
         dst[i] = piece * 1024;
@@ -145,9 +141,9 @@ __device__ __forceinline__ void k64s_store_tile(const GemmParams& p, const f32x4
     }
 }
 
-template <int WM, int WN, int MF, int NF, int NST, int LW, bool DIRECT = false>
+template <int WM, int WN, int MF, int NF, int NST, int LW>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
-    using G = K64SGeo<WM, WN, MF, NF, NST, LW, DIRECT>;
+    using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     if (!shaped_tile(gx, gy, tiles_m, tiles_n, tm, tn)) return;
@@ -168,92 +164,67 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(Gem
     if (wave >= G::NC) {
         k64s_loader_role<G>(reinterpret_cast<const char*>(p.A), reinterpret_cast<const char*>(p.B), p.lda * 2, p.ldb * 2, p.M, p.N, m0, n0, nk,
                             smem, wave - G::NC, lane);
-        if (DIRECT) return;                                                 // the consumers store their own accumulators
     } else {
         // ------------------------------------------------------------------ consumer
         const int frow = lane & 15, fk = lane >> 4;
         const int sw0 = ((fk ^ (frow & 7)) << 4);
         const int a_off = (wm * 16 * MF + frow) * 128;
         const int b_off = G::AOPER + (wn * 16 * NF + frow) * 128;
-        // DIRECT: fragment j of B reads the permuted tile row perm_b_row(frow, j); its swizzle key depends on j's parity only
-        // (NF = 4: rows 16 q + 4 j + r -> key (4 (j & 1) + r) ^ 4 (q >> 1); NF = 5: rows 20 q + 4 j + r -> key 4 ((q + j) & 1) + r)
-        int b_dir[2] = {0, 0};
-        if constexpr (DIRECT) {
-#pragma unroll
-            for (int par = 0; par < 2; ++par) {
-                const int row = wn * 16 * NF + perm_b_row<NF>(frow, par);       // representative of fragments j == par (mod 2)
-                b_dir[par] = G::AOPER + row * 128 + ((fk ^ key_b<NF>(row)) << 4) - par * 512;   // + 512 j below
-            }
-        }
         bf16x8 fa[2][MF], fb[2][NF];
-        auto read_frags = [&](int set, const char* st, int sw, int flip) {
+        auto read_frags = [&](int set, const char* st, int sw) {
 #pragma unroll
             for (int i = 0; i < MF; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(st + a_off + i * 2048 + sw);
 #pragma unroll
-            for (int j = 0; j < NF; ++j) {
-                if constexpr (DIRECT) fb[set][j] = *reinterpret_cast<const bf16x8*>(st + ((b_dir[j & 1] + j * 512) ^ flip));
-                else fb[set][j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 2048 + sw);
-            }
+            for (int j = 0; j < NF; ++j) fb[set][j] = *reinterpret_cast<const bf16x8*>(st + b_off + j * 2048 + sw);
         };
         auto mfma_all = [&](int set) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    if constexpr (DIRECT) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < NF; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
         };
         __builtin_amdgcn_s_barrier();
-        read_frags(0, smem, sw0, 0);
+        read_frags(0, smem, sw0);
         int stage = 0;
         for (int t = 0; t < nk; ++t) {
             const char* st = smem + stage * G::STAGE;
             const int nstage = (stage + 1 == NST) ? 0 : stage + 1;
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);                             // lgkmcnt(0): set 0 complete
-            read_frags(1, st, sw0 ^ 64, 64);
+            read_frags(1, st, sw0 ^ 64);
             mfma_all(0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);                             // set 1 complete: done reading stage t
             if (t + 1 < nk) {
                 __builtin_amdgcn_s_barrier();
-                read_frags(0, smem + nstage * G::STAGE, sw0, 0);
+                read_frags(0, smem + nstage * G::STAGE, sw0);
             }
             mfma_all(1);
             stage = nstage;
         }
     }
-    if constexpr (DIRECT) {
-        // no barrier: every DMA was waited for by its loader before the last K-step's barrier, and nothing is staged through the ring
-        if (p.ablate & 1) {
-            if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[0][0][0];
-            return;
-        }
-        direct_epilogue<bf16_t, MF, NF>(p, acc, m0 + wm * 16 * MF, n0 + wn * 16 * NF, lane);
-    } else {
-        __syncthreads();   // ring free (every DMA was waited for by its loader before the last K-step's barrier)
-        if (p.ablate & 1) {                                                     // keep the accumulators alive without the C pass
-            if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[0][0][0];
-            return;
-        }
-        k64s_store_tile<G, WM, WN, MF, NF>(p, acc, smem, wave, lane, m0, n0);
+    __syncthreads();   // ring free (every DMA was waited for by its loader before the last K-step's barrier)
+    if (p.ablate & 1) {                                                     // keep the accumulators alive without the C pass
+        if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[0][0][0];
+        return;
     }
+    k64s_store_tile<G, WM, WN, MF, NF>(p, acc, smem, wave, lane, m0, n0);
 }
 
-template <int WM, int WN, int MF, int NF, int NST, int LW, bool DIRECT = false>
+template <int WM, int WN, int MF, int NF, int NST, int LW>
 int launch_k64s(const GemmParams& p, hipStream_t stream) {
-    using G = K64SGeo<WM, WN, MF, NF, NST, LW, DIRECT>;
+    using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
     static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
     if (!configured.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, DIRECT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
             return EAVQA_E_LAUNCH;
         configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
-    hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, DIRECT>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
+    hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
                        tiles_m, tiles_n);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
@@ -262,7 +233,7 @@ int launch_k64s(const GemmParams& p, hipStream_t stream) {
 // `rate`: ns per 128-byte operand row and K-step (64) of the fullest CU (calibrated on MI355X with tools/gemm_bench.py).
 struct K64Choice { int bm, bn, wg_per_cu; float rate; int (*launch)(const GemmParams&, hipStream_t); };
 const K64Choice K64_SHAPES[] = {
-    // loader / consumer specialised, LDS-staged epilogue (knob ids 2..)
+    // loader / consumer specialised (knob ids 2..)
     {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 2>},          //  2
     {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 4>},          //  3
     {128, 128, 2, 1.1f, launch_k64s<2, 2, 4, 4, 2, 4>},         //  4
@@ -274,16 +245,10 @@ const K64Choice K64_SHAPES[] = {
     {256, 256, 1, 1.1f, launch_k64s<2, 4, 8, 4, 2, 4>},         // 10
     {128, 128, 1, 1.73f, launch_k64s<2, 2, 4, 4, 3, 2>},        // 11: three stages
     {128, 256, 1, 1.97f, launch_k64s<2, 4, 4, 4, 3, 4>},        // 12
-    // direct epilogue (accumulators -> global without the LDS staging pass; gemm.hip direct_epilogue): what the dispatcher ranks
-    {128, 80, 1, 1.56f, launch_k64s<4, 1, 2, 5, 4, 2, true>},   // 13 = 7 direct
-    {256, 128, 1, 1.97f, launch_k64s<4, 2, 4, 4, 3, 4, true>},  // 14 = 5 direct
-    {256, 160, 1, 1.93f, launch_k64s<4, 2, 4, 5, 3, 4, true>},  // 15 = 6 direct
-    {128, 128, 1, 1.73f, launch_k64s<2, 2, 4, 4, 3, 2, true>},  // 16 = 11 direct
-    {128, 256, 1, 1.97f, launch_k64s<2, 4, 4, 4, 3, 4, true>},  // 17 = 12 direct
 };
 constexpr int N_K64 = sizeof(K64_SHAPES) / sizeof(K64_SHAPES[0]);
-// the tiles the dispatcher chooses among (indices into K64_SHAPES): 128x80 (4 stages), 256x128, 256x160, 128x128 (3 stages), 128x256
-constexpr int K64_AUTO[] = {11, 12, 13, 14, 15};      // table indices of the direct-epilogue builds (knob ids 13..17)
+// the tiles the dispatcher chooses among (indices into K64_SHAPES): s128x80 (4 stages), s256x128, s256x160, s128x128 (3 stages), s128x256
+constexpr int K64_AUTO[] = {5, 3, 4, 9, 10};       // table indices: 128x80 (4 stages), 256x128, 256x160, 128x128 (3 stages), 128x256
 constexpr int N_K64_AUTO = sizeof(K64_AUTO) / sizeof(K64_AUTO[0]);
 
 
