@@ -28,8 +28,9 @@ struct Knobs {
     int big_mode;       // [15:14] round-1 256 x 256 kernel: 0 by shape, 1 never, 2 always (K % 64 == 0)
     int deep;           // [17:16] 2 = force the 8-stage ring of the round-1 128 x 128 kernel (experiment)
     int shape_mode;     // [20:18] round-1 shaped tiles: 0 by cost model, 1 never, 2.. force SHAPES[id - 2]
+    int group_n;        // [24:21] 256 x 256 kernel, tile order inside an XCD: 0 = library default, 1 = m fastest (round 2), 2.. = groups of (value - 1) columns
     explicit Knobs(int k = 0) : stagger(k & 15), ablate((k >> 4) & 7), disable_fast(((k >> 7) & 1) != 0), k64_mode((k >> 8) & 63),
-                                big_mode((k >> 14) & 3), deep((k >> 16) & 3), shape_mode((k >> 18) & 7) {}
+                                big_mode((k >> 14) & 3), deep((k >> 16) & 3), shape_mode((k >> 18) & 7), group_n((k >> 21) & 15) {}
 };
 
 struct GemmParams {
@@ -43,6 +44,7 @@ struct GemmParams {
     int ablate;                    // eavqa_gemm_ex timing-only ablations of the specialised kernels (0 in the product path)
     float alpha;
     int tiles_m, tiles_n;
+    int group_n;                   // 256 x 256 kernel: tile columns per group of the in-XCD tile order (0 = m fastest)
     int vec_c, vec_aux, vec_res, vec_bias;   // 16-byte (8-byte for bf16) vector access allowed on C / aux / residual / bias
 };
 
@@ -811,12 +813,17 @@ inline float tile_cost(const GemmParams& p, int bm, int bn, float rate) {
 //     SIMD, which covers an L2 round trip); one s_barrier per K-tile;
 //   * the C tile leaves through LDS one 64-row slab at a time (the accumulators of one wave row).
 constexpr int GBM = 256, GBN = 256, GBK = 64;
+constexpr int BIG_GROUP_N = 8;                     // tile columns per group of the in-XCD order (tools/gemm_bench.py --group-n sweep, profiles/round3_tile_order.md)
 constexpr int GOPER = GBM * GBK * 2;               // 32 KiB per operand per stage
 constexpr int GSTAGE = 2 * GOPER;                  // 64 KiB
 constexpr int GCS_PITCH = GBN + 4;                 // floats per staged C row
 constexpr int GLDS_BYTES = 2 * GSTAGE;             // 128 KiB (the 64 x 260 fp32 slab reuses it)
 using EpiGeo256 = EpiGeo<64, 16, 4, GCS_PITCH>;    // 64 x 256 slab, 1024 threads
 
+// Order of an XCD's tiles in time (its 32 CUs take them in `local` order): column groups of GN tile columns, inside a group n
+// fastest.  The 32 tiles in flight are then 32 / GN tile rows x GN columns: every A panel is shared by GN concurrent tiles and the
+// group's GN B panels stay in the XCD's L2 while the rows stream by - with m fastest (round 2) a multi-round problem re-read
+// every A panel once per tile column from beyond L2 (FFN-down of the CLIP tower: 4 columns -> the 337 MB A operand four times).
 __device__ __forceinline__ bool big_tile(const GemmParams& p, int gx, int gy, int tiles_m, int tiles_n, int& tm, int& tn) {
     const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
     const int xi = xcd % gx, yi = xcd / gx;
@@ -824,8 +831,17 @@ __device__ __forceinline__ bool big_tile(const GemmParams& p, int gx, int gy, in
     const int m_begin = xi * qm + min(xi, rm), m_cnt = qm + (xi < rm ? 1 : 0);
     const int n_begin = yi * qn + min(yi, rn), n_cnt = qn + (yi < rn ? 1 : 0);
     if (m_cnt == 0 || local >= m_cnt * n_cnt) return false;
-    tm = m_begin + local % m_cnt;
-    tn = n_begin + local / m_cnt;
+    const int GN = p.group_n;
+    if (GN <= 0) {                                     // m fastest (round 2 order; one-round problems do not care)
+        tm = m_begin + local % m_cnt;
+        tn = n_begin + local / m_cnt;
+        return true;
+    }
+    const int per_group = m_cnt * GN;
+    const int g = local / per_group, r = local - g * per_group;
+    const int gn = min(GN, n_cnt - g * GN);           // columns of this (possibly last, narrower) group
+    tm = m_begin + r / gn;
+    tn = n_begin + g * GN + r % gn;
     return true;
 }
 
@@ -1226,6 +1242,7 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = nullptr; p.ablate = kn.ablate;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
     p.act = act; p.out_f32 = out_f32; p.res_lowp = res_lowp; p.out_f16 = stream_f16 && !out_f32; p.alpha = alpha;
+    p.group_n = kn.group_n == 0 ? BIG_GROUP_N : kn.group_n - 1;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     const int esz = dtype == EAVQA_BF16 ? 2 : 4;
@@ -1350,6 +1367,7 @@ extern "C" int eavqa_gemm_fp8(int M, int N, int K, const void* A, int64_t lda, c
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.aux_in = aux_in; p.aux_out = aux_out; p.residual = residual; p.row_scale = a_row_scale; p.ablate = 0;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ld_aux = ld_aux; p.ldr = ldr;
     p.act = act; p.out_f32 = out_f32; p.res_lowp = 0; p.out_f16 = 0; p.alpha = alpha * b_scale;
+    p.group_n = 0;
     p.tiles_m = (M + BM - 1) / BM;
     p.tiles_n = (N + BN - 1) / BN;
     auto vec_ok = [](const void* ptr, int64_t ld, int bytes_per_elem) {

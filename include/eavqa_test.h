@@ -22,7 +22,8 @@ extern "C" {
  *           K64_SHAPES (tile shape x plain / loader-consumer specialised; the table is in that file)
  *   [15:14] round-1 256 x 256 kernel: 0 by shape, 1 never, 2 always (K % 64 == 0)
  *   [17:16] 2 = 8-stage LDS ring of the round-1 128 x 128 kernel (experiment)
- *   [20:18] round-1 shaped tiles: 0 by cost model, 1 never, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192 */
+ *   [20:18] round-1 shaped tiles: 0 by cost model, 1 never, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192
+ *   [24:21] 256 x 256 kernel, order of an XCD's tiles in time: 0 library default, 1 m fastest (round 2), 2..15 column groups of value - 1 */
 int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                   const void* A, int64_t lda, const void* B, int64_t ldb,
                   void* C, int64_t ldc, int out_flags, float alpha,

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--big", type=int, default=0, help="0 auto, 1 never 256x256, 2 always 256x256")
     ap.add_argument("--shape", type=int, default=0, help="0 auto, 1 never a shaped tile, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192")
     ap.add_argument("--k64", type=int, default=0, help="full-line family: 0 by cost model, 1 never (round-1 kernels), 2..12 force K64_SHAPES[id - 2] (csrc/gemm_k64.hip)")
+    ap.add_argument("--group-n", type=int, default=0, help="256 x 256 kernel tile order: 0 default, 1 m fastest, 2.. column groups of value - 1")
     ap.add_argument("--epi", default="", help="epilogue of the timed call: '' plain bf16 out | 'fc1' bias + gelu_new + aux_out | 'quick' bias + quick_gelu | "
                                               "'res32' bias + fp32 residual in place | 'res16' bias + half residual in place | 'bwd' gelu_new derivative at aux_in")
     ap.add_argument("--deep", type=int, default=0, help="8-stage ring: 0 auto, 1 never, 2 always")
@@ -53,7 +54,7 @@ def main():
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
     ops.KernelSelect.gemm = (args.stagger | (args.ablate << 4) | (int(args.general) << 7) | (args.k64 << 8) | (args.big << 14) | (args.deep << 16)
-                             | (args.shape << 18))
+                             | (args.shape << 18) | (args.group_n << 21))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
     for M, N, K, what in SHAPES:
