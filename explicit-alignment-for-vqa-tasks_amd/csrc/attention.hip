@@ -796,6 +796,7 @@ extern "C" int eavqa_attention_bwd_ex(int dtype, int B, int H, int Sq, int Sk, i
         m.B = B; m.H = H; m.Sq = Sq; m.Sk = Sk; m.hd = hd; m.causal = causal; m.stat_ld = Sq;
         m.bsq = Sq; m.bsk = Sk; m.scale = scale;
         if (wide) return eavqa_attn_mfma::run_wide(3, m, s);
+        m.fused_padded = (path & 4) != 0;               // path bit 2: the round-2 padded-pitch one-tile kernel also for hd = 64
         if (Sq <= eavqa_attn_mfma::TILE && Sk <= eavqa_attn_mfma::TILE && !g_split_bwd) return eavqa_attn_mfma::run(3, m, s);
         rc = eavqa_attn_mfma::run(1, m, s);
         if (rc) return rc;

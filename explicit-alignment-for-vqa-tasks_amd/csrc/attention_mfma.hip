@@ -31,6 +31,7 @@ struct Params {
     const int32_t* cu;
     float* lse; float* delta;
     int B, H, Sq, Sk, hd, causal, stat_ld;
+    int fused_padded;              // one-tile backward, hd 64: keep the round-2 padded-pitch kernel (eavqa_attention_bwd_ex path bit 2: A / B, parity)
     int64_t bsq, bsk;
     float scale;
 };
@@ -721,6 +722,186 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(Params p) {
     }
 }
 
+// ------------------------------------------------------------------------------------ backward, one tile, hd = 64: swizzled images
+// The training step's attention backward (GPT-2-large / OPT-1.3B heads, packed sequences of 18 .. 42 positions): the kernel above
+// with (a) 128-byte image rows and the chunk swizzle of the resident forward instead of the 144-byte padded pitch (round 2 measured
+// 69 % of its LDS cycles as bank conflicts): every ds_read_b128 row read and every ds_read_b64_tr_b16 transposed read is
+// conflict-free, the dS image [query][64 keys] uses chunk ^ ((row >> 1) & 7) for its 8-byte row reads; (b) images of R = 16
+// ceil(S / 16) rows only (S = the longest sequence of the launch): 25 KiB at S <= 48 instead of 37 KiB, so five to six workgroups
+// share a CU and the 1 280 problems of a cfg2 step are one round instead of a round and a quarter; (c) only the 16-item fragments that
+// hold items are multiplied.  The dS B fragment of the dQ product is read in the permuted k order of the accumulator-as-B trick, so
+// K^T comes out of the standard transposed-read pattern too.
+__device__ __forceinline__ int ds_off(int row, int key) { return row * 128 + ((((key >> 3) ^ (row >> 1)) & 7) << 4) + (key & 7) * 2; }
+
+__global__ __launch_bounds__(256, 5) void bwd_fused64_kernel(Params p, int R) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* DOs = Qs + R * 128;
+    char* Ks = DOs + R * 128;
+    char* DSs = Ks + R * 128;
+    float* stats = reinterpret_cast<float*>(DSs + R * 128);              // lse[64], delta[64]
+
+    const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
+    if (!window(p, b, 0, false)) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, x = lane & 15, g = lane >> 4;
+    const int item = wave * 16 + x;                   // this lane's key (first half) and query (second half)
+    const int off = p.Sk - p.Sq, head_off = h * 64;
+    const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.q) + p.bsq * p.ldq;
+    const bf16_t* K = reinterpret_cast<const bf16_t*>(p.k) + p.bsk * p.ldk;
+    const bf16_t* V = reinterpret_cast<const bf16_t*>(p.v) + p.bsk * p.ldv;
+    const bf16_t* O = reinterpret_cast<const bf16_t*>(p.o) + p.bsq * p.ldo;
+    const bf16_t* DO = reinterpret_cast<const bf16_t*>(p.d_o) + p.bsq * p.lddo;
+    const int nfq = (p.Sq + 15) >> 4, nfk = (p.Sk + 15) >> 4;            // 16-item fragments that hold a query / a key
+    const bool wave_has_key = wave < nfk, wave_has_query = wave < nfq;
+
+    // stage Q, dO, K: rows < R (rows beyond the sequence zero), chunk c of row r at slot c ^ (r & 6)
+    for (int c = threadIdx.x; c < R * 8; c += 256) {
+        const int r = c >> 3, ch = c & 7, so = res_off(r, ch);
+        uint4 vq = make_uint4(0u, 0u, 0u, 0u), vd = vq, vk = vq;
+        if (r < p.Sq) {
+            vq = *reinterpret_cast<const uint4*>(Q + (int64_t)r * p.ldq + head_off + ch * 8);
+            vd = *reinterpret_cast<const uint4*>(DO + (int64_t)r * p.lddo + head_off + ch * 8);
+        }
+        if (r < p.Sk) vk = *reinterpret_cast<const uint4*>(K + (int64_t)r * p.ldk + head_off + ch * 8);
+        *reinterpret_cast<uint4*>(Qs + so) = vq;
+        *reinterpret_cast<uint4*>(DOs + so) = vd;
+        *reinterpret_cast<uint4*>(Ks + so) = vk;
+    }
+    const bool qa = item < p.Sq, kactive = item < p.Sk;
+    bf16x8 vf[2], of[2];
+    load_bfrag<2>(vf, V, p.ldv, item, kactive, 64, head_off, g);
+    load_bfrag<2>(of, O, p.ldo, item, qa, 64, head_off, g);
+    const int64_t stat_at = ((int64_t)b * p.H + h) * p.stat_ld + item;
+    if (g == 0) stats[item] = qa ? p.lse[stat_at] : 0.f;
+    const bool kvalid = kactive && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + item] != 0);
+    __syncthreads();
+    bf16x8 kf[2];
+    {
+        float dsum = 0.f;
+        if (item < R) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                kf[s] = *reinterpret_cast<const bf16x8*>(Ks + res_off(item, 4 * s + g));
+                const bf16x8 dof = *reinterpret_cast<const bf16x8*>(DOs + res_off(item, 4 * s + g));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) dsum += (float)dof[j] * (float)of[s][j];
+            }
+        } else {
+            kf[0] = zero8(); kf[1] = zero8();
+        }
+        const float delta = group4_sum(dsum);        // rowsum(dO * O) of query `item`
+        if (g == 0) {
+            stats[TILE + item] = qa ? delta : 0.f;
+            if (qa) p.delta[stat_at] = delta;
+        }
+    }
+    __syncthreads();
+
+    const int tq = x >> 2, pp = x & 3;
+    f32x4 sc[4], dp[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { sc[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[f] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+    if (wave_has_key) {
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+            if (f < nfq) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 aq = *reinterpret_cast<const bf16x8*>(Qs + res_off(16 * f + x, 4 * s + g));
+                    const bf16x8 ad = *reinterpret_cast<const bf16x8*>(DOs + res_off(16 * f + x, 4 * s + g));
+                    sc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, kf[s], sc[f], 0, 0, 0);
+                    dp[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, vf[s], dp[f], 0, 0, 0);
+                }
+            }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = 16 * f + 4 * g + r;
+            const bool exists = qq < p.Sq;
+            const bool vis = exists && kvalid && (!p.causal || item <= qq + off);
+            const float pj = exists ? __expf((vis ? sc[f][r] * p.scale : -FLT_MAX) - stats[qq]) : 0.f;
+            sc[f][r] = pj;                                                   // P
+            dp[f][r] = pj * (dp[f][r] - stats[TILE + qq]) * p.scale;        // dS
+            if (qq < R && item < TILE) *reinterpret_cast<bf16_t*>(DSs + ds_off(qq, item)) = (bf16_t)(kactive ? dp[f][r] : 0.f);
+        }
+    if (wave_has_key) {
+        f32x4 dk[4], dv[4];
+#pragma unroll
+        for (int dm = 0; dm < 4; ++dm) { dk[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[dm] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 == 1 && nfq <= 2) break;                                  // queries 32 .. 63 do not exist
+            bf16x8 bp, bd;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                bp[r] = (bf16_t)sc[2 * s2][r]; bp[4 + r] = (bf16_t)sc[2 * s2 + 1][r];
+                bd[r] = (bf16_t)dp[2 * s2][r]; bd[4 + r] = (bf16_t)dp[2 * s2 + 1][r];
+            }
+            const int row_lo = 32 * s2 + 4 * g + tq, sw = row_lo & 6, half = pp >> 1;
+            const int base = row_lo * 128 + 8 * (pp & 1);
+            const bool hi_ok = nfq > 2 * s2 + 1;                             // rows row_lo + 16 lie inside the R-row images
+#pragma unroll
+            for (int dm = 0; dm < 4; ++dm) {
+                const int o = base + (((2 * dm + half) ^ sw) << 4);
+                const bf16x4 lo1 = lds_tr4(DOs + o), lo2 = lds_tr4(Qs + o);
+                bf16x4 hi1 = lo1, hi2 = lo2;                                 // (multiplied by P = dS = 0 when the rows do not exist)
+                if (hi_ok) { hi1 = lds_tr4(DOs + o + 16 * 128); hi2 = lds_tr4(Qs + o + 16 * 128); }
+                bf16x8 a1, a2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a1[r] = lo1[r]; a1[4 + r] = hi1[r]; a2[r] = lo2[r]; a2[4 + r] = hi2[r]; }
+                dv[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bp, dv[dm], 0, 0, 0);
+                dk[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, bd, dk[dm], 0, 0, 0);
+            }
+        }
+        if (kactive) {
+            bf16_t* DK = reinterpret_cast<bf16_t*>(p.dk) + p.bsk * p.lddk;
+            bf16_t* DV = reinterpret_cast<bf16_t*>(p.dv) + p.bsk * p.lddv;
+#pragma unroll
+            for (int dm = 0; dm < 4; ++dm) {
+                store4(DK, p.lddk, item, head_off, 16 * dm + 4 * g, 64, dk[dm], 1.f);
+                store4(DV, p.lddv, item, head_off, 16 * dm + 4 * g, 64, dv[dm], 1.f);
+            }
+        }
+    }
+    __syncthreads();                                  // the dS image is complete
+
+    if (wave_has_query) {
+        f32x4 dq[4];
+#pragma unroll
+        for (int dm = 0; dm < 4; ++dm) dq[dm] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (s2 == 1 && nfk <= 2) break;                                  // keys 32 .. 63 do not exist
+            // dS of query `item`, keys 32 s2 + 4 g .. +3 and 32 s2 + 16 + 4 g .. +3 (the permuted k order of the transposed reads below)
+            const uint2 blo = *reinterpret_cast<const uint2*>(DSs + ds_off(item, 32 * s2 + 4 * g));
+            const uint2 bhi = *reinterpret_cast<const uint2*>(DSs + ds_off(item, 32 * s2 + 16 + 4 * g));
+            const uint4 bb = make_uint4(blo.x, blo.y, bhi.x, bhi.y);
+            const bf16x8 bfrag = __builtin_bit_cast(bf16x8, bb);
+            const int row_lo = 32 * s2 + 4 * g + tq, sw = row_lo & 6, half = pp >> 1;
+            const int base = row_lo * 128 + 8 * (pp & 1);
+            const bool hi_ok = nfk > 2 * s2 + 1;
+#pragma unroll
+            for (int dm = 0; dm < 4; ++dm) {
+                const int o = base + (((2 * dm + half) ^ sw) << 4);
+                const bf16x4 lo = lds_tr4(Ks + o);
+                bf16x4 hi = lo;
+                if (hi_ok) hi = lds_tr4(Ks + o + 16 * 128);
+                bf16x8 a;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
+                dq[dm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bfrag, dq[dm], 0, 0, 0);
+            }
+        }
+        if (qa) {
+            bf16_t* DQ = reinterpret_cast<bf16_t*>(p.dq) + p.bsq * p.lddq;
+#pragma unroll
+            for (int dm = 0; dm < 4; ++dm) store4(DQ, p.lddq, item, head_off, 16 * dm + 4 * g, 64, dq[dm], 1.f);
+        }
+    }
+}
+
 template <int KS, int D16>
 int launch(int which, const Params& p, hipStream_t s) {
     const size_t row = Geo<KS>::ROW_BYTES;
@@ -743,6 +924,9 @@ int launch(int which, const Params& p, hipStream_t s) {
     } else if (which == 1) {
         dim3 grid((p.Sq + TILE - 1) / TILE, p.B * p.H);
         hipLaunchKernelGGL((bwd_dq_kernel<KS, D16>), grid, dim3(256), 2 * row + TILE * 4, s, p);
+    } else if (which == 3 && KS == 2 && !p.fused_padded) {
+        const int R = ((max(p.Sq, p.Sk) + 15) / 16) * 16;
+        hipLaunchKernelGGL(bwd_fused64_kernel, dim3(1, p.B * p.H), dim3(256), (size_t)4 * R * 128 + 2 * TILE * 4, s, p, R);
     } else if (which == 3) {
         static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
         const size_t lds = 3 * row + TILE * (TILE * 2 + 16) + 2 * TILE * 4;

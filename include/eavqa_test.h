@@ -34,7 +34,8 @@ int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
 /* eavqa_attention_fwd / _bwd with a path selector: bit 0 keeps bf16 on the vector-ALU kernels (instead of the matrix-core
  * ones), bit 1 (backward) takes the dQ + dK/dV kernel pair even when the problem is one tile, bit 2 (forward) keeps the
  * streamed-tile matrix-core kernel where the K / V-resident one (hd 64, no mask, Sq == Sk <= 592) would be chosen, bit 3 (forward)
- * takes the resident kernel also for Sk <= 64. */
+ * takes the resident kernel also for Sk <= 64; bit 2 (backward) keeps the round-2 padded-pitch one-tile kernel where the swizzled
+ * hd = 64 one (bwd_fused64_kernel) would be chosen. */
 int eavqa_attention_fwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
                            const void* q, int64_t ldq, const void* k, int64_t ldk,
                            const void* v, int64_t ldv, void* o, int64_t ldo,

@@ -423,6 +423,41 @@ def test_attention_resident_kv_kernel_bf16(ops, B, H, N):
         assert (o2.float().cpu().reshape(B, N, H, hd) - refq.float()).abs().max().item() <= 1e-2 * max(1.0, refq.abs().max().item())
 
 
+@pytest.mark.parametrize("B,H,lens,causal", [(4, 3, [42, 18, 33, 1], True), (3, 2, [64, 49, 16], True), (2, 2, [17, 31], False), (5, 1, [48, 47, 32, 15, 2], True),
+                                              (1, 20, [42], True)])
+def test_attention_one_tile_backward_swizzled_hd64(ops, B, H, lens, causal):
+    """eavqa_attn_mfma::bwd_fused64_kernel (swizzled images of 16 ceil(S / 16) rows, the training step's attention backward) against the
+    float64 reference and the round-2 padded-pitch kernel (path bit 2) on packed sequences of every fragment count (1 .. 64 items)."""
+    hd = 64
+    E = H * hd
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32)
+    M, S = int(cu[-1]), max(lens)
+    qkv = rnd(M, 3 * E, dtype=torch.bfloat16, seed=11)
+    do = rnd(M, E, dtype=torch.bfloat16, seed=12)
+    scale = hd ** -0.5
+    want = []
+    for b in range(B):
+        sl = slice(int(cu[b]), int(cu[b + 1]))
+        q, k, v = (qkv[sl, i * E:(i + 1) * E].double().reshape(1, -1, H, hd).clone().requires_grad_(True) for i in range(3))
+        o = attn_ref(q, k, v, None, causal, scale)
+        o.backward(do[sl].double().reshape(1, -1, H, hd))
+        want.append(tuple(t.grad.reshape(-1, E) for t in (q, k, v)))
+    want = [torch.cat([w[i] for w in want]) for i in range(3)]
+    Q, K, V = (qkv[:, i * E:(i + 1) * E].to(DEV) for i in range(3))
+    o, lse = ops.attention_fwd(Q, K, V, B, H, S, S, hd, causal=causal, scale=scale, save_lse=True, cu_seqlens=cu.to(DEV))
+    got = {}
+    for name, path in (("swizzled", 0), ("padded", 4)):
+        ops.KernelSelect.attention = path
+        try:
+            got[name] = ops.attention_bwd(Q, K, V, o, do.to(DEV), lse, B, H, S, S, hd, causal=causal, scale=scale, cu_seqlens=cu.to(DEV))
+        finally:
+            ops.KernelSelect.attention = 0
+        for g_, w in zip(got[name], want):
+            assert (g_.float().cpu() - w.float()).abs().max().item() <= 6e-2 * max(1.0, w.abs().max().item()), name
+    for a, b_ in zip(got["swizzled"], got["padded"]):
+        assert (a.float() - b_.float()).abs().max().item() <= 2e-2 * max(1.0, b_.float().abs().max().item())
+
+
 @pytest.mark.parametrize("B,H,S,hd", [(2, 2, 42, 200), (1, 3, 64, 640), (2, 1, 5, 136)])
 def test_attention_wide_heads_ragged_chunk_bf16(ops, B, H, S, hd):
     """Head dims the vector-ALU kernels do not cover (GPT-2-xl mapper 1600 / 8 = 200, OPT-13B 5120 / 8 = 640): bf16 only, the last
