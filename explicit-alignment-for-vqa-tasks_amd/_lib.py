@@ -57,6 +57,13 @@ SIGNATURES = {
     "eavqa_vit_assemble": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, i64, ptr],
     "eavqa_cast_rows": [i32, i32, i64, ptr, i64, ptr, i64, ptr],
     "eavqa_quantize_rows_fp8": [i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr],
+    "eavqa_rmsnorm_fwd": [i32, i32, i32, i32, ptr, i64, ptr, f32, ptr, i64, ptr, ptr],
+    "eavqa_rmsnorm_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr],
+    "eavqa_gated_act_fwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr],
+    "eavqa_gated_act_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr],
+    "eavqa_attention_fwd_rel": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i64, i32, f32, ptr, i64, i32, ptr, ptr],
+    "eavqa_attention_bwd_rel": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr, i64,
+                                ptr, i32, f32, ptr, i64, i32, ptr, ptr, ptr],
     "eavqa_gemm_fp8": [i32, i32, i32, ptr, i64, ptr, ptr, i64, f32, ptr, i64, i32, f32, ptr, i32, ptr, ptr, i64, ptr, i64, ptr, i32],
 }
 class LMLayer(C.Structure):

@@ -31,7 +31,15 @@ struct AttnParams {
     int stat_ld;         // row pitch of lse / delta: [B, H, stat_ld]
     int64_t bsq, bsk;   // rows between consecutive batches of q/o/do/dq and of k/v/dk/dv
     float scale;
+    // T5 relative-position bias (eavqa_attention_fwd_rel / _bwd_rel): score(i, j) += rel_bias[h * rel_ld + (j - (i + Sk - Sq)) + rel_zero]
+    const float* rel_bias; int64_t rel_ld; int rel_zero;
 };
+
+__device__ __forceinline__ float rel_term(const AttnParams& p, int h, int i_plus_off, int j) {
+    if (!p.rel_bias) return 0.f;
+    const int idx = min(max((j - i_plus_off) + p.rel_zero, 0), (int)p.rel_ld - 1);      // (rows / keys beyond the sequence: clamped, unused)
+    return p.rel_bias[(int64_t)h * p.rel_ld + idx];
+}
 
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
@@ -124,6 +132,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
                     }
                 }
                 s = group_sum<LPR>(s) * p.scale;
+                if (j < nkeys) s += rel_term(p, h, i + off, k0 + j);
                 const bool vis = (j < nkeys) && valid[j] && (!p.causal || (k0 + j) <= i + off);
                 sc[c] = (j < nkeys) ? (vis ? s : -FLT_MAX) : -INFINITY;   // -inf: key does not exist
                 cmax = fmaxf(cmax, sc[c]);
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
                 s += qv[d].x * kv.x + qv[d].y * kv.y + qv[d].z * kv.z + qv[d].w * kv.w;
                 dp += dov[d].x * vv.x + dov[d].y * vv.y + dov[d].z * vv.z + dov[d].w * vv.w;
             }
-            s = group_sum<LPR>(s) * p.scale;
+            s = group_sum<LPR>(s) * p.scale + rel_term(p, h, i + off, k0 + j);
             dp = group_sum<LPR>(dp);
             const bool vis = valid[j] && (!p.causal || (k0 + j) <= i + off);
             const float pj = expf((vis ? s : -FLT_MAX) - lse);
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
                 s += qq.x * kv[d].x + qq.y * kv[d].y + qq.z * kv[d].z + qq.w * kv[d].w;
                 dp += dd.x * vv[d].x + dd.y * vv[d].y + dd.z * vv[d].z + dd.w * vv[d].w;
             }
-            s = group_sum<LPR>(s) * p.scale;
+            s = group_sum<LPR>(s) * p.scale + rel_term(p, h, i + off, j);
             dp = group_sum<LPR>(dp);
             const bool vis = kvalid && (!p.causal || j <= i + off);
             const float pj = expf((vis ? s : -FLT_MAX) - stats[c]);
@@ -816,4 +825,54 @@ extern "C" int eavqa_attention_bwd(int dtype, int B, int H, int Sq, int Sk, int 
                                    const float* lse, float* delta, void* stream) {
     return eavqa_attention_bwd_ex(dtype, B, H, Sq, Sk, hd, q, ldq, k, ldk, v, ldv, o, ldo, d_o, lddo, dq, lddq, dk, lddk, dv, lddv,
                                   key_mask, cu_seqlens, causal, scale, lse, delta, stream, 0);
+}
+
+// ---------------------------------------------------------------------------------------------------- T5 relative-position bias
+// eavqa_attention_fwd / _bwd with an additive per-head bias that depends on (key position - query position) only: T5's relative
+// attention bias (HF:models/t5/modeling_t5.py:217-279 - compute_bias: values[h][q][k] = table[bucket(k - q)][h], shared by every layer
+// of a stack) handed over as rel_bias[h * rel_ld + (k - q) + rel_zero], float32, q counted from the END of the keys when Sq < Sk (a
+// cached decode step: query i sits at position i + Sk - Sq).  fp32 arithmetic on the vector-ALU kernels for both storage types.
+extern "C" int eavqa_attention_fwd_rel(int dtype, int B, int H, int Sq, int Sk, int hd, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                       const void* v, int64_t ldv, void* o, int64_t ldo, int64_t q_batch_rows, int64_t kv_batch_rows,
+                                       const int32_t* key_mask, int64_t ld_mask, int causal, float scale, const float* rel_bias,
+                                       int64_t rel_ld, int rel_zero, float* lse, void* stream) {
+    if (!q || !k || !v || !o) return EAVQA_E_ARG;
+    int rc = check_common(dtype, B, H, Sq, Sk, hd);
+    if (rc) return rc;
+    if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return EAVQA_E_ALIGN;
+    if (rel_bias && (rel_zero < Sk - 1 || rel_ld < rel_zero + Sk)) return EAVQA_E_ARG;       // the table must span -(Sk - 1) .. Sk - 1
+    AttnParams p = {};
+    p.q = q; p.k = k; p.v = v; p.out = o; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.key_mask = key_mask; p.lse = lse; p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.hd = hd; p.causal = causal; p.scale = scale;
+    p.stat_ld = Sq; p.ld_mask = ld_mask > 0 ? ld_mask : Sk;
+    if (p.ld_mask < Sk) return EAVQA_E_ARG;
+    p.bsq = q_batch_rows > 0 ? q_batch_rows : Sq;
+    p.bsk = kv_batch_rows > 0 ? kv_batch_rows : Sk;
+    if (p.bsq < Sq || p.bsk < Sk) return EAVQA_E_ARG;
+    p.rel_bias = rel_bias; p.rel_ld = rel_ld; p.rel_zero = rel_zero;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return dtype == EAVQA_F32 ? dispatch<float>(K_FWD, p, s) : dispatch<bf16_t>(K_FWD, p, s);
+}
+
+extern "C" int eavqa_attention_bwd_rel(int dtype, int B, int H, int Sq, int Sk, int hd, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                                       const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                                       void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                                       const int32_t* key_mask, int causal, float scale, const float* rel_bias, int64_t rel_ld,
+                                       int rel_zero, const float* lse, float* delta, void* stream) {
+    if (!q || !k || !v || !o || !d_o || !dq || !dk || !dv || !lse || !delta) return EAVQA_E_ARG;
+    int rc = check_common(dtype, B, H, Sq, Sk, hd);
+    if (rc) return rc;
+    if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4 || lddo % 4 || lddq % 4 || lddk % 4 || lddv % 4) return EAVQA_E_ALIGN;
+    if (rel_bias && (rel_zero < Sk - 1 || rel_ld < rel_zero + Sk)) return EAVQA_E_ARG;
+    AttnParams p = {};
+    p.q = q; p.k = k; p.v = v; p.o = o; p.d_o = d_o; p.dq = dq; p.dk = dk; p.dv = dv;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
+    p.key_mask = key_mask; p.lse = const_cast<float*>(lse); p.delta = delta;
+    p.B = B; p.H = H; p.Sq = Sq; p.Sk = Sk; p.hd = hd; p.causal = causal; p.scale = scale;
+    p.bsq = Sq; p.bsk = Sk; p.ld_mask = Sk; p.stat_ld = Sq;
+    p.rel_bias = rel_bias; p.rel_ld = rel_ld; p.rel_zero = rel_zero;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    rc = dtype == EAVQA_F32 ? dispatch<float>(K_DQ, p, s) : dispatch<bf16_t>(K_DQ, p, s);
+    if (rc) return rc;
+    return dtype == EAVQA_F32 ? dispatch<float>(K_DKV, p, s) : dispatch<bf16_t>(K_DKV, p, s);
 }

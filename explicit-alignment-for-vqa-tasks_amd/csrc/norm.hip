@@ -192,6 +192,106 @@ int ln_bwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, c
     return EAVQA_OK;
 }
 
+// T5LayerNorm (HF:models/t5/modeling_t5.py:50-72): y = w * x * rsqrt(mean(x^2) + eps) - no mean subtraction, no bias.  Same row-per-wave
+// layout as ln_fwd_kernel.  Backward (frozen weight): dx = dres + rstd * (g - xhat * mean(g * xhat)), g = w * dy, xhat = x * rstd.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void rms_fwd_kernel(int x_kind, int rows, int cols, const void* x, int64_t ldx, const float* gamma, float eps,
+                                                      T* y, int64_t ldy, float* rstd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = cols >> 2;
+    float4 v[NV], gm[NV];
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = ldrow4<T>(x, (int64_t)row * ldx + 4 * c, x_kind);
+            gm[i] = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0 && rstd) rstd[row] = rs;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) elem<T>::st4(y + (int64_t)row * ldy + 4 * c, make_float4(v[i].x * rs * gm[i].x, v[i].y * rs * gm[i].y, v[i].z * rs * gm[i].z, v[i].w * rs * gm[i].w));
+    }
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void rms_bwd_kernel(int x_kind, int rows, int cols, const void* x, int64_t ldx, const T* dy, int64_t lddy,
+                                                      const float* gamma, const float* rstd, const float* dres, float* dx, int64_t lddx,
+                                                      T* dx_lowp, int64_t ld_lowp) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = cols >> 2;
+    const float rs = rstd[row];
+    float4 xh[NV], gd[NV];
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 xv = ldrow4<T>(x, (int64_t)row * ldx + 4 * c, x_kind);
+            const float4 d = elem<T>::ld4(dy + (int64_t)row * lddy + 4 * c);
+            const float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
+            xh[i] = make_float4(xv.x * rs, xv.y * rs, xv.z * rs, xv.w * rs);
+            gd[i] = make_float4(d.x * g.x, d.y * g.y, d.z * g.z, d.w * g.w);
+            s2 += (gd[i].x * xh[i].x + gd[i].y * xh[i].y) + (gd[i].z * xh[i].z + gd[i].w * xh[i].w);
+        } else {
+            xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            gd[i] = xh[i];
+        }
+    }
+    const float m2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const float4 r = dres ? *reinterpret_cast<const float4*>(dres + (int64_t)row * lddx + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 o;
+            o.x = r.x + rs * (gd[i].x - xh[i].x * m2);
+            o.y = r.y + rs * (gd[i].y - xh[i].y * m2);
+            o.z = r.z + rs * (gd[i].z - xh[i].z * m2);
+            o.w = r.w + rs * (gd[i].w - xh[i].w * m2);
+            *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + 4 * c) = o;
+            if (dx_lowp) elem<T>::st4(dx_lowp + (int64_t)row * ld_lowp + 4 * c, o);
+        }
+    }
+}
+
+template <typename T>
+int rms_fwd_dispatch(int x_kind, int rows, int cols, const void* x, int64_t ldx, const float* gamma, float eps, void* y, int64_t ldy, float* rstd,
+                     hipStream_t s) {
+    const int nv = (cols / 4 + 63) / 64;
+    dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(256);
+#define EAVQA_RMS_FWD(NV) hipLaunchKernelGGL((rms_fwd_kernel<T, NV>), grid, block, 0, s, x_kind, rows, cols, x, ldx, gamma, eps, reinterpret_cast<T*>(y), ldy, rstd)
+    if (nv <= 2) EAVQA_RMS_FWD(2); else if (nv <= 4) EAVQA_RMS_FWD(4); else if (nv <= 8) EAVQA_RMS_FWD(8); else if (nv <= 16) EAVQA_RMS_FWD(16); else EAVQA_RMS_FWD(32);
+#undef EAVQA_RMS_FWD
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+template <typename T>
+int rms_bwd_dispatch(int x_kind, int rows, int cols, const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* gamma, const float* rstd,
+                     const float* dres, float* dx, int64_t lddx, void* dx_lowp, int64_t ld_lowp, hipStream_t s) {
+    const int nv = (cols / 4 + 63) / 64;
+    dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(256);
+#define EAVQA_RMS_BWD(NV) hipLaunchKernelGGL((rms_bwd_kernel<T, NV>), grid, block, 0, s, x_kind, rows, cols, x, ldx, reinterpret_cast<const T*>(dy), lddy, \
+                                             gamma, rstd, dres, dx, lddx, reinterpret_cast<T*>(dx_lowp), ld_lowp)
+    if (nv <= 2) EAVQA_RMS_BWD(2); else if (nv <= 4) EAVQA_RMS_BWD(4); else if (nv <= 8) EAVQA_RMS_BWD(8); else if (nv <= 16) EAVQA_RMS_BWD(16);
+    else return EAVQA_E_SHAPE;
+#undef EAVQA_RMS_BWD
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
 }  // namespace
 
 extern "C" int eavqa_layernorm_fwd(int dtype, int x_kind, int rows, int cols, const void* x, int64_t ldx,
@@ -220,5 +320,30 @@ extern "C" int eavqa_layernorm_bwd(int dtype, int x_f32, int rows, int cols, con
         return ln_bwd_dispatch<float>(1, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta, dx_lowp, ld_lowp, s);
     if (dtype == EAVQA_BF16)
         return ln_bwd_dispatch<bf16_t>(x_f32, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta, dx_lowp, ld_lowp, s);
+    return EAVQA_E_DTYPE;
+}
+
+extern "C" int eavqa_rmsnorm_fwd(int dtype, int x_kind, int rows, int cols, const void* x, int64_t ldx, const float* gamma, float eps,
+                                 void* y, int64_t ldy, float* rstd, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0) return EAVQA_E_ARG;
+    if (cols % 4 || cols > 64 * 4 * LN_MAX_V4) return EAVQA_E_SHAPE;
+    if (ldx % 4 || ldy % 4) return EAVQA_E_ALIGN;
+    if (x_kind < 0 || x_kind > 3) return EAVQA_E_DTYPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32) return rms_fwd_dispatch<float>(x_kind == 0 ? 1 : x_kind, rows, cols, x, ldx, gamma, eps, y, ldy, rstd, s);
+    if (dtype == EAVQA_BF16) return rms_fwd_dispatch<bf16_t>(x_kind, rows, cols, x, ldx, gamma, eps, y, ldy, rstd, s);
+    return EAVQA_E_DTYPE;
+}
+
+extern "C" int eavqa_rmsnorm_bwd(int dtype, int x_kind, int rows, int cols, const void* x, int64_t ldx, const void* dy, int64_t lddy,
+                                 const float* gamma, const float* rstd, const float* dres, float* dx, int64_t lddx, void* dx_lowp,
+                                 int64_t ld_lowp, void* stream) {
+    if (!x || !dy || !dx || !rstd || rows <= 0 || cols <= 0) return EAVQA_E_ARG;
+    if (cols % 4) return EAVQA_E_SHAPE;
+    if (ldx % 4 || lddy % 4 || lddx % 4 || (dx_lowp && ld_lowp % 4)) return EAVQA_E_ALIGN;
+    if (x_kind < 0 || x_kind > 3) return EAVQA_E_DTYPE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32) return rms_bwd_dispatch<float>(x_kind == 0 ? 1 : x_kind, rows, cols, x, ldx, dy, lddy, gamma, rstd, dres, dx, lddx, dx_lowp, ld_lowp, s);
+    if (dtype == EAVQA_BF16) return rms_bwd_dispatch<bf16_t>(x_kind, rows, cols, x, ldx, dy, lddy, gamma, rstd, dres, dx, lddx, dx_lowp, ld_lowp, s);
     return EAVQA_E_DTYPE;
 }

@@ -2,6 +2,7 @@
 // the HBM-bound gathers that build the residual stream.  One wavefront per batch row does the
 // prefix scans (sentinel counts, OPT position ids, first-pad / seen-<BOS> flags).
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -577,3 +578,61 @@ extern "C" int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x
     return EAVQA_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------- gated activation (T5 v1.1 / T0)
+// T5DenseGatedActDense (HF:models/t5/modeling_t5.py:97-123): h = act(wi_0 x) * (wi_1 x).  The two projections are ONE GEMM against the
+// stacked weight [wi_0; wi_1] -> u [rows, 2 F]; forward: h[:, c] = act(u[:, c]) * u[:, F + c]; backward (frozen weights, dgrad only):
+// du[:, c] = dh * u[:, F + c] * act'(u[:, c]),  du[:, F + c] = dh * act(u[:, c]).  HBM-bound elementwise passes, 4 columns per thread.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void gated_act_fwd_kernel(int rows, int F, int act, const T* u, int64_t ldu, T* h, int64_t ldh) {
+    const int64_t n4 = (int64_t)rows * (F >> 2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (F >> 2);
+        const int c = (int)(i - r * (F >> 2)) * 4;
+        const float4 a = elem<T>::ld4(u + r * ldu + c), b = elem<T>::ld4(u + r * ldu + F + c);
+        elem<T>::st4(h + r * ldh + c, make_float4(act_fwd(act, a.x) * b.x, act_fwd(act, a.y) * b.y, act_fwd(act, a.z) * b.z, act_fwd(act, a.w) * b.w));
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gated_act_bwd_kernel(int rows, int F, int act, const T* u, int64_t ldu, const T* dh, int64_t lddh, T* du,
+                                                            int64_t lddu) {
+    const int64_t n4 = (int64_t)rows * (F >> 2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / (F >> 2);
+        const int c = (int)(i - r * (F >> 2)) * 4;
+        const float4 a = elem<T>::ld4(u + r * ldu + c), b = elem<T>::ld4(u + r * ldu + F + c), d = elem<T>::ld4(dh + r * lddh + c);
+        elem<T>::st4(du + r * lddu + c, make_float4(d.x * b.x * act_bwd(act, a.x), d.y * b.y * act_bwd(act, a.y), d.z * b.z * act_bwd(act, a.z),
+                                                    d.w * b.w * act_bwd(act, a.w)));
+        elem<T>::st4(du + r * lddu + F + c, make_float4(d.x * act_fwd(act, a.x), d.y * act_fwd(act, a.y), d.z * act_fwd(act, a.z), d.w * act_fwd(act, a.w)));
+    }
+}
+}  // namespace
+
+extern "C" int eavqa_gated_act_fwd(int dtype, int rows, int F, int act, const void* u, int64_t ldu, void* h, int64_t ldh, void* stream) {
+    if (!u || !h || rows <= 0 || F <= 0) return EAVQA_E_ARG;
+    if (F % 4 || ldu % 4 || ldh % 4 || ldu < 2 * F || ldh < F) return EAVQA_E_SHAPE;
+    if (act < EAVQA_ACT_NONE || act > EAVQA_ACT_QUICK_GELU) return EAVQA_E_DTYPE;
+    const int64_t n4 = (int64_t)rows * (F / 4);
+    const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 256 * 8);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32) hipLaunchKernelGGL(gated_act_fwd_kernel<float>, dim3(blocks), dim3(256), 0, s, rows, F, act, reinterpret_cast<const float*>(u), ldu, reinterpret_cast<float*>(h), ldh);
+    else if (dtype == EAVQA_BF16) hipLaunchKernelGGL(gated_act_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, rows, F, act, reinterpret_cast<const bf16_t*>(u), ldu, reinterpret_cast<bf16_t*>(h), ldh);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+extern "C" int eavqa_gated_act_bwd(int dtype, int rows, int F, int act, const void* u, int64_t ldu, const void* dh, int64_t lddh, void* du,
+                                   int64_t lddu, void* stream) {
+    if (!u || !dh || !du || rows <= 0 || F <= 0) return EAVQA_E_ARG;
+    if (F % 4 || ldu % 4 || lddh % 4 || lddu % 4 || ldu < 2 * F || lddu < 2 * F || lddh < F) return EAVQA_E_SHAPE;
+    if (act < EAVQA_ACT_NONE || act > EAVQA_ACT_QUICK_GELU) return EAVQA_E_DTYPE;
+    const int64_t n4 = (int64_t)rows * (F / 4);
+    const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 256 * 8);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_F32) hipLaunchKernelGGL(gated_act_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, rows, F, act, reinterpret_cast<const float*>(u), ldu, reinterpret_cast<const float*>(dh), lddh, reinterpret_cast<float*>(du), lddu);
+    else if (dtype == EAVQA_BF16) hipLaunchKernelGGL(gated_act_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, rows, F, act, reinterpret_cast<const bf16_t*>(u), ldu, reinterpret_cast<const bf16_t*>(dh), lddh, reinterpret_cast<bf16_t*>(du), lddu);
+    else return EAVQA_E_DTYPE;
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}

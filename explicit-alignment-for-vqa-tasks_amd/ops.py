@@ -465,3 +465,70 @@ def scatter_rows(src: Tensor, idx: Tensor, rows: int) -> Tensor:
     out = torch.zeros((rows, src.shape[1]), device=src.device, dtype=src.dtype)
     call("eavqa_move_rows", dtype_id(src.dtype), 1, idx.shape[0], src.shape[1], _p(src), _ld(src), _p(idx), _p(out), _ld(out), _stream())
     return out
+
+
+# ----------------------------------------------------------------------------------------------------- T5 / T0 (models/t5.py)
+_X_KIND = {torch.float32: 1, torch.bfloat16: 2, torch.float16: 3}
+
+
+def rmsnorm_fwd(x: Tensor, gamma: Optional[Tensor], eps: float, out_dtype: torch.dtype, save_stats: bool = False):
+    """T5LayerNorm rows of ``x`` -> ``y`` in ``out_dtype`` (+ rstd)."""
+    _dev(x)
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), device=x.device, dtype=out_dtype)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32) if save_stats else None
+    call("eavqa_rmsnorm_fwd", dtype_id(out_dtype), _X_KIND[x.dtype], rows, cols, _p(x), _ld(x), _p(gamma), float(eps), _p(y), _ld(y), _p(rstd), _stream())
+    return (y, rstd) if save_stats else y
+
+
+def rmsnorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], rstd: Tensor, dres: Optional[Tensor] = None, out: Optional[Tensor] = None,
+                lowp_out: Optional[Tensor] = None) -> Tensor:
+    _dev(x)
+    rows, cols = x.shape
+    dx = out if out is not None else torch.empty((rows, cols), device=x.device, dtype=torch.float32)
+    if dres is not None and _ld(dres) != _ld(dx):
+        raise _lib.EavqaError("dres must share dx's leading dimension")
+    call("eavqa_rmsnorm_bwd", dtype_id(dy.dtype), _X_KIND[x.dtype], rows, cols, _p(x), _ld(x), _p(dy), _ld(dy), _p(gamma), _p(rstd), _p(dres),
+         _p(dx), _ld(dx), _p(lowp_out), _ld(lowp_out) if lowp_out is not None else 0, _stream())
+    return dx
+
+
+def gated_act_fwd(u: Tensor, act: str) -> Tensor:
+    """``u`` [rows, 2F] -> ``act(u[:, :F]) * u[:, F:]`` [rows, F]."""
+    _dev(u)
+    rows, F2 = u.shape
+    h = torch.empty((rows, F2 // 2), device=u.device, dtype=u.dtype)
+    call("eavqa_gated_act_fwd", dtype_id(u.dtype), rows, F2 // 2, ACT[act], _p(u), _ld(u), _p(h), _ld(h), _stream())
+    return h
+
+
+def gated_act_bwd(u: Tensor, dh: Tensor, act: str) -> Tensor:
+    rows, F2 = u.shape
+    du = torch.empty_like(u)
+    call("eavqa_gated_act_bwd", dtype_id(u.dtype), rows, F2 // 2, ACT[act], _p(u), _ld(u), _p(dh), _ld(dh), _p(du), _ld(du), _stream())
+    return du
+
+
+def attention_fwd_rel(q: Tensor, k: Tensor, v: Tensor, B: int, H: int, Sq: int, Sk: int, hd: int, *, rel_bias: Optional[Tensor], rel_zero: int = 0,
+                      key_mask: Optional[Tensor] = None, causal: bool = False, scale: float = 1.0, save_lse: bool = False,
+                      q_batch_rows: int = 0, kv_batch_rows: int = 0, ld_mask: int = 0):
+    """Attention with T5's relative-position bias table ``rel_bias`` [H, n_offsets] float32 (offset key - query at column + rel_zero)."""
+    _dev(q)
+    o = torch.empty((B * Sq, H * hd), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32) if save_lse else None
+    call("eavqa_attention_fwd_rel", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), q_batch_rows,
+         kv_batch_rows, _p(key_mask), ld_mask, int(causal), float(scale), _p(rel_bias), rel_bias.stride(0) if rel_bias is not None else 0,
+         int(rel_zero), _p(lse), _stream())
+    return (o, lse) if save_lse else o
+
+
+def attention_bwd_rel(q, k, v, o, d_o, lse, B, H, Sq, Sk, hd, *, rel_bias=None, rel_zero=0, key_mask=None, causal=False, scale=1.0):
+    _dev(q)
+    dq = torch.empty((B * Sq, H * hd), device=q.device, dtype=q.dtype)
+    dk = torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
+    dv = torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
+    delta = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
+    call("eavqa_attention_bwd_rel", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(d_o), _ld(d_o),
+         _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(key_mask), int(causal), float(scale), _p(rel_bias),
+         rel_bias.stride(0) if rel_bias is not None else 0, int(rel_zero), _p(lse), _p(delta), _stream())
+    return dq, dk, dv

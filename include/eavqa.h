@@ -330,6 +330,33 @@ int eavqa_gemm_fp8(int M, int N, int K, const void* A, int64_t lda, const float*
                    float b_scale, void* C, int64_t ldc, int out_f32, float alpha, const float* bias, int act,
                    const void* aux_in, void* aux_out, int64_t ld_aux, const float* residual, int64_t ldr, void* stream, int tile);
 
+/* ------------------------------------------------------------- T5 / T0 encoder-decoder (VCT0Model, src/models/vct0.py:301-491) ---
+ * T5LayerNorm (HF:models/t5/modeling_t5.py:50-72): y = gamma * x * rsqrt(mean(x^2) + eps); no mean subtraction, no bias.
+ * x_kind as in eavqa_layernorm_fwd (1 float32, 0 `dtype`, 2 bfloat16, 3 half); rstd float32 [rows] or NULL. */
+int eavqa_rmsnorm_fwd(int dtype, int x_kind, int rows, int cols, const void* x, int64_t ldx, const float* gamma, float eps,
+                      void* y, int64_t ldy, float* rstd, void* stream);
+/* dx = (dres ? dres : 0) + RMSNorm'(dy) (float32; dres may alias dx), frozen gamma; dx_lowp: optional copy of dx in `dtype`. */
+int eavqa_rmsnorm_bwd(int dtype, int x_kind, int rows, int cols, const void* x, int64_t ldx, const void* dy, int64_t lddy,
+                      const float* gamma, const float* rstd, const float* dres, float* dx, int64_t lddx, void* dx_lowp,
+                      int64_t ld_lowp, void* stream);
+/* T5DenseGatedActDense (HF:models/t5/modeling_t5.py:97-123): u [rows, 2F] = x @ [wi_0; wi_1]^T (one eavqa_gemm);
+ * fwd: h[:, c] = act(u[:, c]) * u[:, F + c];  bwd: du[:, c] = dh * u[:, F + c] * act'(u[:, c]), du[:, F + c] = dh * act(u[:, c]). */
+int eavqa_gated_act_fwd(int dtype, int rows, int F, int act, const void* u, int64_t ldu, void* h, int64_t ldh, void* stream);
+int eavqa_gated_act_bwd(int dtype, int rows, int F, int act, const void* u, int64_t ldu, const void* dh, int64_t lddh,
+                        void* du, int64_t lddu, void* stream);
+/* eavqa_attention_fwd / _bwd with T5's relative-position bias (HF:models/t5/modeling_t5.py:217-279, added to the unscaled scores,
+ * :312-350): score(i, j) += rel_bias[h * rel_ld + (j - (i + Sk - Sq)) + rel_zero] (float32 table per head over key - query
+ * offsets, at least -(Sk - 1) .. Sk - 1; NULL = no bias: the cross-attention).  No packed (cu_seqlens) form.  fp32 arithmetic. */
+int eavqa_attention_fwd_rel(int dtype, int B, int H, int Sq, int Sk, int hd, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                            const void* v, int64_t ldv, void* o, int64_t ldo, int64_t q_batch_rows, int64_t kv_batch_rows,
+                            const int32_t* key_mask, int64_t ld_mask, int causal, float scale, const float* rel_bias,
+                            int64_t rel_ld, int rel_zero, float* lse, void* stream);
+int eavqa_attention_bwd_rel(int dtype, int B, int H, int Sq, int Sk, int hd, const void* q, int64_t ldq, const void* k, int64_t ldk,
+                            const void* v, int64_t ldv, const void* o, int64_t ldo, const void* d_o, int64_t lddo,
+                            void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                            const int32_t* key_mask, int causal, float scale, const float* rel_bias, int64_t rel_ld,
+                            int rel_zero, const float* lse, float* delta, void* stream);
+
 /* float32 -> `dtype` elementwise copy with row strides (casts the residual stream / pooled rows). */
 int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream);
 

@@ -25,6 +25,8 @@ __all__ = [
     "lm_logits", "causal_lm_loss", "clipcap_forward", "clipcap_generate",
     "label_mask_vqa", "label_mask_cc", "insert_prefix_into_input",
     "clip_vit_encode", "adamw_step", "mapper_project",
+    "t5_rms_norm", "t5_relative_bucket", "t5_position_bias", "t5_encoder", "t5_decoder", "t5_lm_logits", "t5_shift_right",
+    "vct0_forward", "vct0_generate",
 ]
 
 
@@ -437,3 +439,181 @@ def adamw_step(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, step: int, lr:
     bc2 = 1 - beta2 ** step
     denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
     param.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# --------------------------------------------------------------------------
+# T5 / T0 encoder-decoder and VCT0Model (src/models/vct0.py:301-491)
+# --------------------------------------------------------------------------
+def t5_rms_norm(x: Tensor, w: Tensor, eps: float = 1e-6) -> Tensor:
+    """``T5LayerNorm`` HF:models/t5/modeling_t5.py:50-72: no mean subtraction, no bias."""
+    return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+
+
+def t5_relative_bucket(rel: Tensor, bidirectional: bool, num_buckets: int = 32, max_distance: int = 128) -> Tensor:
+    """``T5Attention._relative_position_bucket`` HF:...modeling_t5.py:217-262 (rel = key position - query position)."""
+    out = torch.zeros_like(rel)
+    if bidirectional:
+        num_buckets //= 2
+        out = out + (rel > 0).long() * num_buckets
+        rel = rel.abs()
+    else:
+        rel = -torch.min(rel, torch.zeros_like(rel))
+    max_exact = num_buckets // 2
+    is_small = rel < max_exact
+    large = max_exact + (torch.log(rel.float() / max_exact) / math.log(max_distance / max_exact) * (num_buckets - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    return out + torch.where(is_small, rel, large)
+
+
+def t5_position_bias(table: Tensor, q_len: int, k_len: int, bidirectional: bool, q_offset: int = 0, max_distance: int = 128) -> Tensor:
+    """``compute_bias`` HF:...modeling_t5.py:264-279: ``[1, H, q_len, k_len]`` from the ``[num_buckets, H]`` embedding of the FIRST layer of
+    a stack (shared by all its layers); ``q_offset`` = tokens already in the cache."""
+    ctx = torch.arange(q_len)[:, None] + q_offset
+    mem = torch.arange(k_len)[None, :]
+    b = t5_relative_bucket(mem - ctx, bidirectional, table.shape[0], max_distance)
+    return table[b].permute(2, 0, 1)[None]
+
+
+def _t5_attention(sd, pre: str, x: Tensor, kv: Tensor, bias: Tensor, H: int, dkv: int) -> Tensor:
+    """``T5Attention.forward`` HF:...modeling_t5.py:281-369: q / k / v / o without bias, scores NOT scaled, ``bias`` (position bias +
+    additive mask) added before the softmax."""
+    B, S, _ = x.shape
+    Sk = kv.shape[1]
+    q = (x @ sd[pre + "q.weight"].T).view(B, S, H, dkv).transpose(1, 2)
+    k = (kv @ sd[pre + "k.weight"].T).view(B, Sk, H, dkv).transpose(1, 2)
+    v = (kv @ sd[pre + "v.weight"].T).view(B, Sk, H, dkv).transpose(1, 2)
+    w = torch.softmax(q @ k.transpose(-1, -2) + bias, dim=-1)
+    return (w @ v).transpose(1, 2).reshape(B, S, H * dkv) @ sd[pre + "o.weight"].T
+
+
+def _t5_ffn(sd, pre: str, x: Tensor, cfg: dict) -> Tensor:
+    """``T5DenseActDense`` (:75-94, relu) or ``T5DenseGatedActDense`` (:97-123, gelu_new(wi_0 x) * wi_1 x)."""
+    if cfg.get("gated", True):
+        return (gelu_new(x @ sd[pre + "wi_0.weight"].T) * (x @ sd[pre + "wi_1.weight"].T)) @ sd[pre + "wo.weight"].T
+    return torch.relu(x @ sd[pre + "wi.weight"].T) @ sd[pre + "wo.weight"].T
+
+
+def t5_encoder(sd, cfg: dict, inputs_embeds: Tensor, attention_mask: Optional[Tensor] = None) -> Tensor:
+    """``T5Stack`` (encoder) HF:...modeling_t5.py:640-751: blocks of [RMSNorm -> self-attention + residual, RMSNorm -> FFN + residual],
+    final RMSNorm; bidirectional relative bias from block 0; padded keys get ``finfo.min`` added."""
+    B, S, _ = inputs_embeds.shape
+    H, dkv, eps = cfg["n_head"], cfg["d_kv"], cfg.get("eps", 1e-6)
+    if attention_mask is None:
+        attention_mask = torch.ones(B, S, dtype=torch.long)
+    bias = t5_position_bias(sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], S, S, True,
+                            max_distance=cfg.get("max_distance", 128))
+    bias = bias + torch.where(attention_mask[:, None, None, :] != 0, 0.0, NEG)
+    h = inputs_embeds
+    for i in range(cfg["n_layer"]):
+        p = f"encoder.block.{i}.layer."
+        h = h + _t5_attention(sd, p + "0.SelfAttention.", t5_rms_norm(h, sd[p + "0.layer_norm.weight"], eps), t5_rms_norm(h, sd[p + "0.layer_norm.weight"], eps), bias, H, dkv)
+        h = h + _t5_ffn(sd, p + "1.DenseReluDense.", t5_rms_norm(h, sd[p + "1.layer_norm.weight"], eps), cfg)
+    return t5_rms_norm(h, sd["encoder.final_layer_norm.weight"], eps)
+
+
+def t5_decoder(sd, cfg: dict, dec_embeds: Tensor, enc_out: Tensor, enc_mask: Optional[Tensor] = None) -> Tensor:
+    """``T5Stack`` (decoder): causal self-attention with the unidirectional relative bias of block 0, cross-attention over the encoder
+    output (zero position bias, encoder padding masked), FFN; final RMSNorm."""
+    B, T, _ = dec_embeds.shape
+    S = enc_out.shape[1]
+    H, dkv, eps = cfg["n_head"], cfg["d_kv"], cfg.get("eps", 1e-6)
+    n_dec = cfg.get("n_dec_layer", cfg["n_layer"])
+    if enc_mask is None:
+        enc_mask = torch.ones(B, S, dtype=torch.long)
+    self_bias = t5_position_bias(sd["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], T, T, False,
+                                 max_distance=cfg.get("max_distance", 128))
+    self_bias = self_bias + torch.where(torch.ones(T, T, dtype=torch.bool).tril()[None, None], 0.0, NEG)
+    cross_bias = torch.where(enc_mask[:, None, None, :] != 0, 0.0, NEG).expand(B, 1, T, S)
+    h = dec_embeds
+    for i in range(n_dec):
+        p = f"decoder.block.{i}.layer."
+        a = t5_rms_norm(h, sd[p + "0.layer_norm.weight"], eps)
+        h = h + _t5_attention(sd, p + "0.SelfAttention.", a, a, self_bias, H, dkv)
+        h = h + _t5_attention(sd, p + "1.EncDecAttention.", t5_rms_norm(h, sd[p + "1.layer_norm.weight"], eps), enc_out, cross_bias, H, dkv)
+        h = h + _t5_ffn(sd, p + "2.DenseReluDense.", t5_rms_norm(h, sd[p + "2.layer_norm.weight"], eps), cfg)
+    return t5_rms_norm(h, sd["decoder.final_layer_norm.weight"], eps)
+
+
+def t5_lm_logits(sd, cfg: dict, dec_hidden: Tensor) -> Tensor:
+    """``T5ForConditionalGeneration.forward`` HF:...modeling_t5.py:1040-1048: tied embeddings rescale the decoder output by d_model^-0.5
+    and use ``shared`` as the head (T5 v1.0); v1.1 / T0 have their own ``lm_head``."""
+    if cfg.get("tied", False):
+        return (dec_hidden * dec_hidden.shape[-1] ** -0.5) @ sd["shared.weight"].T
+    return dec_hidden @ sd["lm_head.weight"].T
+
+
+def t5_shift_right(labels: Tensor, start_id: int = 0, pad_id: int = 0) -> Tensor:
+    """``_shift_right`` HF:...modeling_t5.py:618-637: ``[start, labels[:-1]]`` with -100 -> pad."""
+    out = torch.full_like(labels, start_id)
+    out[:, 1:] = labels[:, :-1]
+    return out.masked_fill(out == -100, pad_id)
+
+
+def vct0_forward(sd, cfg: dict, mapper, mcfg: dict, prefix: Tensor, labels: Tensor):
+    """``VCT0Model.forward`` src/models/vct0.py:380-394: the encoder sees ONLY the projected prefix (``inputs_embeds``), the decoder is
+    teacher-forced on ``labels``; loss = CE over labels != -100 (HF:...modeling_t5.py:1050-1056).  Returns ``(loss, logits [B, T, V])``."""
+    E = sd["shared.weight"].shape[1]
+    pre = mapper_project(prefix, mapper, mcfg.get("mapping_type", "mlp"), mcfg["prefix_length"], E, mcfg.get("clip_length"), mcfg.get("num_layers", 8))
+    enc = t5_encoder(sd, cfg, pre)
+    dec_in = sd["shared.weight"][t5_shift_right(labels, cfg.get("decoder_start_token_id", 0), cfg.get("pad_token_id", 0))]
+    logits = t5_lm_logits(sd, cfg, t5_decoder(sd, cfg, dec_in, enc))
+    loss = torch.nn.functional.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1), ignore_index=-100)
+    return loss, logits
+
+
+def _t5_greedy(sd, cfg: dict, enc: Tensor, enc_mask: Optional[Tensor], max_length: int, dec_prompt: Optional[Tensor] = None):
+    """HF greedy search for an encoder-decoder (``GenerationMixin._sample`` with do_sample=False): start token = decoder_start_token_id
+    (= pad = 0 for T5), every step re-runs the decoder over the whole prefix (same logits as the cached run), rows that produced eos (1)
+    emit pad afterwards, stop when all rows are finished or ``max_length`` TOTAL decoder positions exist.  Returns
+    ``(sequences [B, <= max_length], per-step logits list)``."""
+    B = enc.shape[0]
+    start, pad, eos = cfg.get("decoder_start_token_id", 0), cfg.get("pad_token_id", 0), cfg.get("eos_token_id", 1)
+    seq = torch.full((B, 1), start, dtype=torch.long) if dec_prompt is None else dec_prompt.clone()
+    unfinished = torch.ones(B, dtype=torch.long)
+    scores = []
+    while seq.shape[1] < max_length:
+        logits = t5_lm_logits(sd, cfg, t5_decoder(sd, cfg, sd["shared.weight"][seq], enc, enc_mask))[:, -1]
+        scores.append(logits)
+        nxt = logits.argmax(-1) * unfinished + pad * (1 - unfinished)
+        seq = torch.cat([seq, nxt[:, None]], dim=1)
+        unfinished = unfinished * (nxt != eos).long()
+        if unfinished.max() == 0:
+            break
+    return seq, scores
+
+
+def vct0_generate(sd, cfg: dict, mapper, mcfg: dict, prefix: Tensor, question_tokens: Optional[Tensor] = None,
+                  question_mask: Optional[Tensor] = None, num_shots: Optional[int] = None, max_length: int = 20,
+                  special_token_id: int = 32099, one_at_a_time: bool = False, no_prefix: bool = False):
+    """``VCT0Model.generate`` src/models/vct0.py:396-491 (greedy, HF defaults):
+      * ``question_tokens is None`` (:485-491, the CC executor): the encoder sees the projected prefix only;
+      * few-shot (:452-466): sentinel tokens ``special_token_id - i`` of the prompt are replaced by the L prefix vectors of image i
+        (``insert_prefix_into_input`` :494-533), one encoder pass over the joint sequence;
+      * ``one_at_a_time`` (:426-442): question_tokens ``[B, n, T]``; example i is encoded by itself with sentinel ``special - i``, the
+        encoder outputs and masks are concatenated along the sequence before decoding;
+      * ``no_prefix`` (:409-424, text only): plain T5 generate on the tokens.
+    Returns ``(sequences, scores)``."""
+    E, L = sd["shared.weight"].shape[1], mcfg["prefix_length"]
+    proj = lambda p: mapper_project(p, mapper, mcfg.get("mapping_type", "mlp"), L, E, mcfg.get("clip_length"), mcfg.get("num_layers", 8))
+    if no_prefix:
+        enc = t5_encoder(sd, cfg, sd["shared.weight"][question_tokens], question_mask)
+        return _t5_greedy(sd, cfg, enc, question_mask, max_length)
+    if question_tokens is None:
+        enc = t5_encoder(sd, cfg, proj(prefix))
+        return _t5_greedy(sd, cfg, enc, None, max_length)
+    B = question_tokens.shape[0]
+    if one_at_a_time:
+        n = prefix.shape[1]
+        pp = proj(prefix.reshape(-1, prefix.shape[-1])).view(B, n, L, E)
+        encs, masks = [], []
+        for i in range(n):
+            emb, msk = insert_prefix_into_input(L, 0, question_tokens[:, i], sd["shared.weight"][question_tokens[:, i]], pp[:, i], question_mask[:, i],
+                                                special_token_id - i)
+            encs.append(t5_encoder(sd, cfg, emb, msk))
+            masks.append(msk)
+        return _t5_greedy(sd, cfg, torch.cat(encs, 1), torch.cat(masks, 1), max_length)
+    n_img = prefix.shape[1] if prefix.dim() >= 3 else 1
+    ns = (n_img - 1) if not num_shots else num_shots
+    pp = proj(prefix.reshape(-1, prefix.shape[-1])).view(B, -1, L, E)
+    emb, msk = insert_prefix_into_input(L, ns, question_tokens, sd["shared.weight"][question_tokens], pp, question_mask, special_token_id)
+    return _t5_greedy(sd, cfg, t5_encoder(sd, cfg, emb, msk), msk, max_length)

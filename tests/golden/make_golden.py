@@ -28,6 +28,7 @@ Known-answer tables that need no execution (label masking, restated from
 imported here) are written from hand-derived expectations.
 """
 import os
+import shutil
 import sys
 import tempfile
 import types
@@ -297,6 +298,98 @@ def main():
         emb = clip(pixel_values=px).image_embeds
     save("clip_vit_p14.npz", cfg=np.array([64, 128, 1, 4, 42, 14, 24]), pixels=px.numpy(), image_embeds=emb.numpy(),
          **_np(clip.state_dict(), "w."))
+
+
+def vct0_golden():
+    """The reference's own ``VCT0Prefix`` (src/models/vct0.py:301-549) on two tiny random-init ``T5ForConditionalGeneration`` saved locally
+    (``model_version=<directory>``): v1.1 / T0 style (gated gelu_new FFN, untied lm_head) and v1.0 style (ReLU FFN, tied embeddings with the
+    d_model^-0.5 rescale).  Outputs: ``forward(prefix, labels)`` loss / logits / mapper gradients (the CC training step of
+    src/trainers/vct0_exector.py:143-146), and greedy ``generate`` ids + per-step scores for (a) the prefix-only path (:485-491), (b) the
+    few-shot interleaved path (:452-466), (c) one example at a time (:426-442), (d) text only (:409-424).  The reference hard-codes T5's
+    sentinel id 32099 in ``generate``; the tiny vocabulary has none, so the subclass below maps ``special_token_id`` 32099 - i to V - 1 - i
+    before delegating - the function under test is otherwise the reference's."""
+    clipcap, vct0 = _import_reference()
+    from transformers import T5Config, T5ForConditionalGeneration
+    tmp = tempfile.mkdtemp(prefix="eavqa_vct0_")
+    V, E, DKV, H, F, NL, L, D = 96, 64, 16, 4, 128, 2, 3, 24
+    out = {}
+    for tag, gated, tied in (("t0", True, False), ("t5v10", False, True)):
+        torch.manual_seed(2021)
+        cfg = T5Config(vocab_size=V, d_model=E, d_kv=DKV, num_heads=H, d_ff=F, num_layers=NL, num_decoder_layers=NL, dropout_rate=0.0,
+                       feed_forward_proj="gated-gelu" if gated else "relu", tie_word_embeddings=tied, decoder_start_token_id=0, pad_token_id=0,
+                       eos_token_id=1, relative_attention_num_buckets=32, relative_attention_max_distance=128)
+        cfg._attn_implementation = "eager"
+        lm = T5ForConditionalGeneration(cfg).eval()
+        g = torch.Generator().manual_seed(7)
+        with torch.no_grad():                  # HF initialises the layer norms to ones and biases the init by a factor: make every tensor informative
+            for n, p in lm.named_parameters():
+                if "layer_norm" in n:
+                    p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=g))
+                elif "relative_attention_bias" in n:
+                    p.copy_(0.5 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(p * 1.0 + 0.05 * torch.randn(p.shape, generator=g))
+        path = os.path.join(tmp, tag)
+        lm.save_pretrained(path)
+
+        class TinyVCT0(vct0.VCT0Prefix):
+            def insert_prefix_into_input(self, *a, special_token_id=32099, **k):
+                return super().insert_prefix_into_input(*a, special_token_id=special_token_id - 32099 + (V - 1), **k)
+
+        torch.manual_seed(2021)
+        model = TinyVCT0(prefix_length=L, prefix_size=D, mapping_type="mlp", model_version=path).eval()
+        model.lm.config._attn_implementation = "eager"
+        sd = {k: v.detach().clone() for k, v in model.lm.state_dict().items()}
+        gen = torch.Generator().manual_seed(11)
+        # ---- forward(prefix, labels): CC training step
+        B, T = 3, 7
+        prefix = torch.randn(B, D, generator=gen)
+        labels = torch.randint(2, V - 8, (B, T), generator=gen)
+        labels[1, 5:] = -100
+        labels[2, 3:] = -100
+        labels[0, T - 1] = 1                                      # eos
+        res = model(prefix=prefix, labels=labels)
+        res.loss.backward()
+        arrs = dict(cfg=np.array([V, E, DKV, H, F, NL, L, D, int(gated), int(tied)]), prefix=prefix.numpy(), labels=labels.numpy(),
+                    loss=res.loss.detach().numpy(), logits=res.logits.detach().numpy())
+        arrs.update(_np(sd, "lm."))
+        arrs.update(_np(model.clip_project.state_dict(), "map."))
+        arrs.update({"gmap." + n: p.grad.numpy() for n, p in model.clip_project.named_parameters()})
+        # ---- generate: prefix only
+        kw = dict(max_length=9, output_scores=True, return_dict_in_generate=True, do_sample=False, num_beams=1)
+        with torch.no_grad():
+            o = model.generate(prefix=prefix, **kw)
+        arrs["gen_prefix_ids"] = o.sequences.numpy()
+        arrs["gen_prefix_scores"] = torch.stack(o.scores).numpy()
+        # ---- generate: few-shot (2 shots + query = 3 images), ragged right padding
+        n_img, Tq = 3, 12
+        q = torch.randint(2, V - 8, (B, Tq), generator=gen)
+        for b_ in range(B):
+            for i, pos in enumerate(sorted(torch.randperm(Tq - 3, generator=gen)[:n_img].tolist())):
+                q[b_, pos] = V - 1 - i
+        qm = torch.ones(B, Tq, dtype=torch.long)
+        qm[1, Tq - 2:] = 0
+        q[1, Tq - 2:] = 0
+        pf = torch.randn(B, n_img, 1, D, generator=gen)
+        with torch.no_grad():
+            o = model.generate(prefix=pf, question_tokens=q, question_mask=qm, **kw)
+        arrs.update(fs_tokens=q.numpy(), fs_mask=qm.numpy(), fs_prefix=pf.numpy(), gen_fs_ids=o.sequences.numpy(), gen_fs_scores=torch.stack(o.scores).numpy())
+        # ---- generate: one example at a time (each [B, n, T1] row holds ONE sentinel, V - 1 - i for example i)
+        T1 = 6
+        q1 = torch.randint(2, V - 8, (B, n_img, T1), generator=gen)
+        for i in range(n_img):
+            q1[:, i, 1 + i] = V - 1 - i
+        qm1 = torch.ones(B, n_img, T1, dtype=torch.long)
+        qm1[2, 1, T1 - 1] = 0
+        with torch.no_grad():
+            o = model.generate(prefix=pf, question_tokens=q1, question_mask=qm1, pass_examples_through_encoder_one_at_a_time=True, **kw)
+        arrs.update(one_tokens=q1.numpy(), one_mask=qm1.numpy(), gen_one_ids=o.sequences.numpy(), gen_one_scores=torch.stack(o.scores).numpy())
+        # ---- generate: text only
+        with torch.no_grad():
+            o = model.generate(prefix=pf, question_tokens=q, question_mask=qm, no_prefix=True, **kw)
+        arrs.update(gen_text_ids=o.sequences.numpy(), gen_text_scores=torch.stack(o.scores).numpy())
+        save(f"vct0_{tag}.npz", **arrs)
+    shutil.rmtree(tmp, ignore_errors=True)
 
 
 def _install_import_stubs():
@@ -605,6 +698,9 @@ def module_parser_golden():
 
 
 if __name__ == "__main__":
+    if "--vct0-only" in sys.argv:
+        vct0_golden()
+        sys.exit(0)
     if "--module-parser-only" in sys.argv:
         module_parser_golden()
         sys.exit(0)
@@ -622,3 +718,4 @@ if __name__ == "__main__":
         vqa_eval_golden()
         dropin_golden()
         module_parser_golden()
+        vct0_golden()
