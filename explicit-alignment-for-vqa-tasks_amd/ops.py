@@ -522,11 +522,12 @@ def attention_fwd_rel(q: Tensor, k: Tensor, v: Tensor, B: int, H: int, Sq: int, 
     return (o, lse) if save_lse else o
 
 
-def attention_bwd_rel(q, k, v, o, d_o, lse, B, H, Sq, Sk, hd, *, rel_bias=None, rel_zero=0, key_mask=None, causal=False, scale=1.0):
+def attention_bwd_rel(q, k, v, o, d_o, lse, B, H, Sq, Sk, hd, *, rel_bias=None, rel_zero=0, key_mask=None, causal=False, scale=1.0,
+                      dq=None, dk=None, dv=None):
     _dev(q)
-    dq = torch.empty((B * Sq, H * hd), device=q.device, dtype=q.dtype)
-    dk = torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
-    dv = torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
+    dq = dq if dq is not None else torch.empty((B * Sq, H * hd), device=q.device, dtype=q.dtype)
+    dk = dk if dk is not None else torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
+    dv = dv if dv is not None else torch.empty((B * Sk, H * hd), device=q.device, dtype=q.dtype)
     delta = torch.empty((B, H, Sq), device=q.device, dtype=torch.float32)
     call("eavqa_attention_bwd_rel", dtype_id(q.dtype), B, H, Sq, Sk, hd, _p(q), _ld(q), _p(k), _ld(k), _p(v), _ld(v), _p(o), _ld(o), _p(d_o), _ld(d_o),
          _p(dq), _ld(dq), _p(dk), _ld(dk), _p(dv), _ld(dv), _p(key_mask), int(causal), float(scale), _p(rel_bias),
