@@ -26,6 +26,18 @@ def test_own_configs_evaluate_and_select_classes_by_name():
     assert few.data_loader.additional.num_shots == 4 and few.mode == "test"
 
 
+def test_t0_configs_select_the_vct0_classes_by_name():
+    """The T5 / T0 path's configs (the reference's headline model, configs/vqa2/few_shot_vqa_hotpotqa.jsonnet and
+    configs/conceptual_captions/conceptual_captions.jsonnet): ModelClass and executor are found by name in the executor module."""
+    from eavqa_amd.trainers import vct0_executor
+    few = cs.load_config(os.path.join(ROOT, "configs", "vqa2", "few_shot_vqa_t0_3b.jsonnet"), mode="test")
+    cc = cs.load_config(os.path.join(ROOT, "configs", "conceptual_captions", "vct0_t0_3b.jsonnet"))
+    for cfg in (few, cc):
+        assert cfg.model_config.ModelClass == "VCT0Prefix" and hasattr(vct0_executor, cfg.model_config.ModelClass) and hasattr(vct0_executor, cfg.train.type)
+        assert dict(cfg.model_config.model_args)["model_version"] == "bigscience/T0_3B"
+    assert few.data_loader.additional.num_shots == 2 and cc.train.additional.gradient_accumulation_steps == 4
+
+
 def test_merge_patch_semantics():
     assert cs.merge_patch({"a": {"b": 1, "c": 2}, "d": 3}, {"a": {"b": None, "e": 5}, "d": [1]}) == {"a": {"c": 2, "e": 5}, "d": [1]}
     assert cs.evaluate_snippet("local x = 2; local y = {a: x, 'b': [1, x,], }; std.mergePatch(y, {b: null, c: 'q' + \"r\"})") == {"a": 2, "c": "qr"}

@@ -327,3 +327,52 @@ def test_cfg5_fp8_training_step_real_size():
     # activations flip ReLU derivatives through 32 layers (tests/test_fp8_numerics_model.py: the gradient operand's format is not the cause)
     # measured on MI355X (round 3): cosine 0.926, norm ratio 1.005
     assert cos >= 0.88 and 0.93 <= ratio <= 1.07, (cos, ratio)
+
+
+def test_vct0_t0_3b_real_size_training_step():
+    """The reference's CC training configuration at its real LM size (configs/conceptual_captions/conceptual_captions.jsonnet: VCT0Prefix over
+    bigscience/T0_3B = T5-XL v1.1: 24 + 24 blocks, d_model 2048, 32 heads x 64, gated-gelu FFN 5120, untied head; prefix 10, MLP mapper):
+    loss / logits / mapper gradients of one step (B = 2, 8 caption tokens) against the CPU oracle, fp32 (1e-3) and bf16."""
+    import time
+    from eavqa_amd.models.t5 import KNOWN_T5, FrozenT5, T5Config, random_init_t5_state_dict
+    from eavqa_amd.models.vct0 import VCT0Prefix
+    t0 = time.time()
+    cfg = T5Config.from_hf_dict(KNOWN_T5["bigscience/T0_3B"])
+    sd = {k: v.cpu() for k, v in random_init_t5_state_dict(cfg, 2021, DEV).items()}
+    g = torch.Generator().manual_seed(5)
+    for k in sd:
+        if "layer_norm" in k:
+            sd[k] = sd[k] + 0.05 * torch.randn(sd[k].shape, generator=g)
+    sd["shared.weight"] = sd["shared.weight"] * 0.3            # HF initialises T5 embeddings at std 1: keep activations in a realistic range
+    L, D, B, T = 10, 768, 2, 8
+    labels = torch.randint(2, cfg.vocab - 200, (B, T), generator=g)
+    labels[1, 5:] = -100
+    prefix = torch.randn(B, D, generator=g)
+    res, mapper_sd = {}, None
+    for dtype in (torch.float32, torch.bfloat16):
+        lm = FrozenT5(cfg, sd, dtype, DEV)
+        torch.manual_seed(2021)
+        model = VCT0Prefix(prefix_length=L, prefix_size=D, mapping_type="mlp", lm=lm, dtype=dtype, device=DEV).train()
+        if mapper_sd is None:
+            mapper_sd = {k: v.detach().float().cpu().clone() for k, v in model.clip_project.state_dict().items()}
+        else:
+            model.clip_project.load_state_dict(mapper_sd)
+        out = model(prefix=prefix, labels=labels)
+        out.loss.backward()
+        res[dtype] = (out.loss.item(), out.logits.float().cpu(), {k: p.grad.float().cpu() for k, p in model.clip_project.named_parameters()})
+        del model, lm
+        torch.cuda.empty_cache()
+    t1 = time.time()
+    mp = {k: v.clone().requires_grad_(True) for k, v in mapper_sd.items()}
+    ocfg = dict(n_layer=cfg.n_layer, n_dec_layer=cfg.n_dec_layer, n_head=cfg.n_head, d_kv=cfg.d_kv, gated=True, tied=False)
+    loss, logits = oracle.vct0_forward(sd, ocfg, mp, dict(prefix_length=L, mapping_type="mlp"), prefix, labels)
+    loss.backward()
+    want = {k: p.grad for k, p in mp.items()}
+    for dtype, (tl, tg_cos) in ((torch.float32, (1e-3, 0.99999)), (torch.bfloat16, (8e-2, 0.99))):
+        l, lg, gr = res[dtype]
+        e_log = (lg - logits.detach()).abs().max().item()
+        cos, ratio, maxrel = grad_stats(gr, want)
+        print(f"[T0_3B {dtype}] |d loss| {abs(l - loss.item()):.2e} (loss {loss.item():.4f})  max|d logits| {e_log:.2e} (|logits| max {logits.abs().max().item():.2f})  "
+              f"gradient cosine {cos:.6f}  norm ratio {ratio:.5f}  max rel {maxrel:.2e}   [GPU {t1 - t0:.0f} s, CPU {time.time() - t1:.0f} s]")
+        assert abs(l - loss.item()) <= (1e-4 if dtype == torch.float32 else 2e-2) and e_log <= tl * max(1.0, logits.abs().max().item())
+        assert cos >= tg_cos and abs(ratio - 1) <= (1e-3 if dtype == torch.float32 else 3e-2)

@@ -183,3 +183,60 @@ def test_vct0_prefix_trains_only_the_mapper_and_decoder_prompt_path():
     o = model.generate(prefix=T(z["fs_prefix"]), question_tokens=T(z["one_tokens"])[:, 0].contiguous() * 0 + T(z["one_tokens"])[:, 0],
                        question_mask=T(z["one_mask"])[:, 0], decoder_input_ids=prompt, special_token_id=V - 1, max_length=8)
     assert o.shape[0] == 3 and o.shape[1] <= 8 - 3
+
+
+def test_vct0_executors_from_config_train_and_generate():
+    """``VCT0Executor`` / ``FewShotVQAExecutor`` constructed from this build's jsonnet configs (model injected: the tiny reference-fixture
+    T5): a two-step ``fit`` lowers the loss; the few-shot generative step reproduces the reference's ids on the plain path, and the
+    permutation ensemble picks, per question, the member the CPU oracle's scores pick (few_shot_vqa_executor.py:293-332)."""
+    import os
+    import numpy as np
+    from eavqa_amd.trainers.vct0_executor import FewShotVQAExecutor, VCT0Executor
+    from eavqa_amd.utils import config_system as cs
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    z, T, model, V = _model("t0", torch.float32)
+    cfg = cs.load_config(os.path.join(root, "configs", "conceptual_captions", "vct0_t0_3b.jsonnet"))
+    assert cfg.model_config.ModelClass == "VCT0Prefix" and cfg.train.type == "VCT0Executor"
+    ex = VCT0Executor(cfg, model=model, dtype=torch.float32, device=DEV)
+    batch = {"clip_embeddings": T(z["prefix"]), "labels": T(z["labels"])}
+    losses = ex.fit([batch] * 6, accumulate_grad_batches=1)
+    assert abs(losses[0].item() - float(z["loss"])) <= 2e-4 and losses[-1].item() < losses[0].item()
+    step = ex._generative_step({**batch, "image_urls": ["u"] * 3}, 0)
+    assert len(step["predictions"]) == 3 and step["outputs"].shape[0] == 3
+    # few-shot executor on a fresh copy of the fixture weights (fit above moved the mapper)
+    z, T, model, V = _model("t0", torch.float32)
+    model.eval()
+    few = cs.load_config(os.path.join(root, "configs", "vqa2", "few_shot_vqa_t0_3b.jsonnet"), mode="test",
+                         opts=[f"data_loader.additional.special_token_id={V - 1}", "data_loader.additional.max_target_length=9"])
+    assert few.train.type == "FewShotVQAExecutor"
+    fx = FewShotVQAExecutor(few, model=model, dtype=torch.float32, device=DEV)
+    plain = fx._generative_step({"generative_input_ids": T(z["fs_tokens"]), "generative_attention_mask": T(z["fs_mask"]), "clip_embeddings": T(z["fs_prefix"]),
+                                 "labels": T(z["labels"])}, 0)
+    assert torch.equal(plain["outputs"], T(z["gen_fs_ids"]))
+    # permutation ensemble: two "permutations" = the fixture prompt and the same prompt with images 0 and 1 swapped in the embeddings
+    few.data_loader.additional.num_permutations_of_in_context_examples = 2
+    toks = torch.stack([T(z["fs_tokens"]), T(z["fs_tokens"])], dim=1)               # [B, 2, T]
+    msk = torch.stack([T(z["fs_mask"]), T(z["fs_mask"])], dim=1)
+    pf = T(z["fs_prefix"])[:, :, 0]                                                 # [B, 3, D]
+    emb = torch.stack([pf, pf[:, [1, 0, 2]]], dim=1)                                # [B, 2, 3, D]
+    ens = fx._generative_step({"generative_input_ids": toks.reshape(-1, toks.shape[-1]), "generative_attention_mask": msk.reshape(-1, msk.shape[-1]),
+                               "clip_embeddings": emb, "labels": T(z["labels"])}, 0)
+    sd = {k[3:]: T(v) for k, v in z.items() if k.startswith("lm.")}
+    V_, E, DKV, H, F, NL, L, D, gated, tied = [int(v) for v in z["cfg"]]
+    ocfg = dict(n_layer=NL, n_head=H, d_kv=DKV, gated=bool(gated), tied=bool(tied))
+    mapper = {k[4:]: T(v) for k, v in z.items() if k.startswith("map.")}
+    want = []
+    scores = np.zeros((3, 2))
+    seqs = []
+    with torch.no_grad():
+        for i in range(2):
+            seq, sc = oracle.vct0_generate(sd, ocfg, mapper, dict(prefix_length=L, mapping_type="mlp"), emb[:, i], toks[:, i], msk[:, i], max_length=9,
+                                           special_token_id=V - 1)
+            logp = torch.log(torch.stack(sc).softmax(-1))
+            for j, s_ in enumerate(seq.tolist()):
+                scores[j, i] = sum(float(logp[k - 1, j, t]) for k, t in enumerate(s_) if t not in (0, 1, 2))
+            seqs.append(seq)
+    for j, ind in enumerate(np.argmax(scores, axis=1)):
+        gap = abs(scores[j, 0] - scores[j, 1])
+        if gap > 1e-2:
+            assert ens["outputs"][j].tolist() == seqs[ind][j].tolist(), (j, scores[j])
