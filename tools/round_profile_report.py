@@ -4,7 +4,10 @@
   <out>_mfma.md                          per GEMM / attention kernel: MFMA-busy % (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024
                                          SIMDs), the box's MfmaUtil expression), LDS bank-conflict and LDS-issue-stall shares
   gemm traffic json                      via tools/pmc_traffic.py (FETCH_SIZE x 2 + WRITE_SIZE, KiB)
-usage: round_profile_report.py <prof_dir> <out_prefix> <traffic_json> "<command>" """
+  <out>_hbm.md                           the HBM-bound kernels (LayerNorm fwd / bwd, CE fwd / bwd, AdamW, fp8 row quantiser, transposes): algorithmic
+                                         bytes per launch (bench.py --hbm-bytes-out: every operand read once, every result written once) / the
+                                         kernel's average duration in the rocprofv3 kernel trace / 8 TB/s
+usage: round_profile_report.py <prof_dir> <out_prefix> <traffic_json> "<command>" [<hbm_bytes_json>] """
 import collections
 import csv
 import glob
@@ -14,6 +17,7 @@ import subprocess
 import sys
 
 prof, out, traffic_json, command = sys.argv[1:5]
+hbm_json = sys.argv[5] if len(sys.argv) > 5 else None
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -39,6 +43,32 @@ with open(out + ".md", "w") as f:
             "`at::native::*` rows are the one-time random initialisation of the weights).\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
     for r in rows[:28]:
         f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.2f} | {float(r['AverageNs'])/1e3:.1f} | {float(r['Percentage']):.1f} |\n")
+
+# ---- HBM-bound kernels: algorithmic bytes (bench.py's byte model of the same step) over rocprof's kernel durations
+if hbm_json and os.path.exists(hbm_json):
+    import json
+    model = json.load(open(hbm_json))
+    steps = None
+    with open(out + "_hbm.md", "w") as f:
+        f.write(f"# HBM-bound kernels of one step: algorithmic bytes / rocprofv3 average kernel duration / 8 TB/s\n\nCommand: `{command}` under "
+                "`rocprofv3 --kernel-trace --stats` (durations); bytes per launch from `bench.py --hbm-bytes-out` on the same workload "
+                f"({model['workload']} {model['dtype']}): every operand read once, every result written once.  An op that runs as several kernels "
+                "(CE forward: row pass + reduction) is priced against the sum of their time.\n\n"
+                "| op | kernels matched | launches / step | bytes / launch | avg kernel us | GB/s | of 8 TB/s |\n|---|---|---|---|---|---|---|\n")
+        for op, m in model["ops"].items():
+            hit = [r for r in rows if m["kernel_pattern"] in r["Name"]]
+            if not hit:
+                continue
+            total_ns = sum(float(r["TotalDurationNs"]) for r in hit)
+            counts = {int(r["Calls"]) for r in hit}
+            # several kernels with EQUAL call counts = one op launch runs all of them (CE forward: row pass + reduction); different counts =
+            # template variants, one per launch (LayerNorm of two widths)
+            launches = counts.pop() if (len(hit) > 1 and len(counts) == 1) else sum(int(r["Calls"]) for r in hit)
+            per_launch_us = total_ns / 1e3 / launches
+            bytes_per = m["bytes_per_step"] / m["launches_per_step"]
+            gbs = bytes_per / per_launch_us / 1e3
+            names = ", ".join(sorted({short(r["Name"])[:40] for r in hit}))
+            f.write(f"| `eavqa_{op}` | `{names}` | {m['launches_per_step']} | {bytes_per / 1e6:.2f} MB | {per_launch_us:.2f} | {gbs:.0f} | {gbs / 8000:.3f} |\n")
 
 # ---- MFMA busy
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
