@@ -31,6 +31,8 @@ SHAPES = [  # (M, N, K, what)
     (2048, 3072, 5120, "probe 384 tiles"), (2048, 4096, 5120, "probe 512 tiles"), (4096, 4096, 5120, "probe 1024 tiles"),
     (41120, 3072, 1024, "vitL qkv"), (41120, 1024, 1024, "vitL proj"), (41120, 4096, 1024, "vitL fc1"), (41120, 1024, 4096, "vitL fc2"),
     (4800, 7680, 2560, "prefill qkv"), (4800, 2560, 2560, "prefill proj"), (4800, 10240, 2560, "prefill fc1"), (4800, 2560, 10240, "prefill fc2"),
+    (41120, 4096, 64, "kslope 64"), (41120, 4096, 256, "kslope 256"), (41120, 4096, 512, "kslope 512"), (41120, 4096, 2048, "kslope 2048"),
+    (41120, 4096, 4096, "kslope 4096"), (41120, 4096, 4160, "kslope 4160 (odd pitch)"), (41120, 4096, 1088, "kslope 1088 (odd pitch)"), (41120, 4096, 1024, "kslope 1024"), (40960, 4096, 1024, "kslope full tiles 1024"), (8192, 8192, 1024, "one round 1024"), (8192, 8192, 4096, "one round 4096"),
     (3200, 3072, 768, "vit fc1"), (3200, 768, 3072, "vit fc2"), (4096, 4096, 4096, "square 4k"), (8192, 8192, 8192, "square 8k"),
 ]
 
