@@ -851,6 +851,21 @@ extern "C" int eavqa_attention_fwd_rel(int dtype, int B, int H, int Sq, int Sk, 
     if (p.bsq < Sq || p.bsk < Sk) return EAVQA_E_ARG;
     p.rel_bias = rel_bias; p.rel_ld = rel_ld; p.rel_zero = rel_zero;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // bf16 at an MFMA head size: the streamed-tile MFMA kernel adds the bias to its score tile (T0_3B few-shot: the vector-ALU kernel
+    // was 27 % of the GPU time, 71 us per call); without a bias this is eavqa_attention_fwd (T5's cross-attention)
+    if (dtype == EAVQA_BF16 && !rel_bias)
+        return attention_fwd_impl(dtype, B, H, Sq, Sk, hd, q, ldq, k, ldk, v, ldv, o, ldo, q_batch_rows, kv_batch_rows, key_mask, ld_mask,
+                                  nullptr, causal, scale, lse, stream, 0, nullptr, nullptr, 0);
+    if (dtype == EAVQA_BF16 && eavqa_attn_mfma::supported(hd) && !(ldq % 8 || ldk % 8 || ldv % 8) && eavqa_aligned16(q) && eavqa_aligned16(k) &&
+        eavqa_aligned16(v)) {
+        eavqa_attn_mfma::Params m = {};
+        m.q = q; m.k = k; m.v = v; m.out = o; m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo;
+        m.key_mask = key_mask; m.ld_mask = p.ld_mask; m.cu = nullptr; m.lse = lse;
+        m.B = B; m.H = H; m.Sq = Sq; m.Sk = Sk; m.hd = hd; m.causal = causal; m.stat_ld = Sq;
+        m.bsq = p.bsq; m.bsk = p.bsk; m.scale = scale;
+        m.rel_bias = rel_bias; m.rel_ld = rel_ld; m.rel_zero = rel_zero;
+        return eavqa_attn_mfma::run(0, m, s);
+    }
     return dtype == EAVQA_F32 ? dispatch<float>(K_FWD, p, s) : dispatch<bf16_t>(K_FWD, p, s);
 }
 

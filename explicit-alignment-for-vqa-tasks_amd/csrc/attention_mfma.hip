@@ -34,6 +34,8 @@ struct Params {
     int fused_padded;              // one-tile backward, hd 64: keep the round-2 padded-pitch kernel (eavqa_attention_bwd_ex path bit 2: A / B, parity)
     int64_t bsq, bsk;
     float scale;
+    // T5 relative-position bias (forward, streamed-tile kernel only): score(i, j) += rel_bias[h * rel_ld + (j - (i + Sk - Sq)) + rel_zero]
+    const float* rel_bias; int64_t rel_ld; int rel_zero;
 };
 
 constexpr int TILE = 64;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
         tile_dot<KS>(st, Ks, qf, x, g, nf);
         // a full tile without a mask (every tile but the last of the CLIP tower's 257 tokens): no per-key tests, and the scale moves
         // into the exponent - exp((s - m) scale) = exp2(s c - m c'), two instructions per score instead of ten
-        const bool plain_tile = !p.causal && !p.key_mask && k0 + TILE <= p.Sk && p.scale > 0.f;
+        const bool plain_tile = !p.causal && !p.key_mask && !p.rel_bias && k0 + TILE <= p.Sk && p.scale > 0.f;
         float m_new;
         if (plain_tile) {
             float tmax = -FLT_MAX;
@@ -241,6 +243,9 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
                 for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, st[f][r]);
             m_new = fmaxf(m, group4_max(tmax) * p.scale);
         } else {
+            // the bias table of this head, shifted so that the key position indexes it (entries outside the table: clamped, never visible)
+            const float* rel = p.rel_bias ? p.rel_bias + (int64_t)h * p.rel_ld : nullptr;
+            const int rel_shift = p.rel_zero - (qi + off), rel_last = (int)p.rel_ld - 1;
             float tmax = -FLT_MAX;
 #pragma unroll
             for (int f = 0; f < 4; ++f)
@@ -249,7 +254,9 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
                     const int kk = 16 * f + 4 * g + r;          // key within the tile
                     const bool exists = k0 + kk < p.Sk;
                     const bool vis = valid[kk] && (!p.causal || (k0 + kk) <= qi + off);
-                    st[f][r] = exists ? (vis ? st[f][r] * p.scale : -FLT_MAX) : -INFINITY;
+                    float sv = st[f][r] * p.scale;
+                    if (rel) sv += rel[min(max(k0 + kk + rel_shift, 0), rel_last)];
+                    st[f][r] = exists ? (vis ? sv : -FLT_MAX) : -INFINITY;
                     tmax = fmaxf(tmax, st[f][r]);
                 }
             m_new = fmaxf(m, group4_max(tmax));

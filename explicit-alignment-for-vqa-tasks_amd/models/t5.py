@@ -372,6 +372,10 @@ class FrozenT5:
         raw = torch.empty(B, dtype=torch.int32, device=self.device)
         unfinished = torch.ones(B, dtype=torch.int32, device=self.device)
         scores = [] if output_scores else None
+        # `alive[t]` = some row still unfinished after position t was written.  The host looks at it every fourth step only (one
+        # device -> host round trip per step would keep the launch queue empty); positions written after every row had finished hold
+        # pad and are cut off below, so the result is the one of a check after every step.
+        alive = torch.ones(max(max_length, P) + 1, dtype=torch.int32, device=self.device)
         t = P
         while t < max_length:
             y = self.embed(seq[:, :t].contiguous())
@@ -379,9 +383,15 @@ class FrozenT5:
             last = hid.view(B, t, c.d_model)[:, -1].contiguous()
             lg = self.logits(last)
             if output_scores:
-                scores.append(lg[:, :c.vocab].float().cpu())
+                scores.append(lg[:, :c.vocab].float())
             ops.greedy_pick(lg, c.vocab, c.pad_token_id, c.eos_token_id, raw, seq[:, t], unfinished)      # emitted token = what is fed back
+            torch.amax(unfinished, dim=0, out=alive[t])
             t += 1
-            if int(unfinished.max().item()) == 0:
+            if (t - P) % 4 == 0 and int(alive[t - 1].item()) == 0:
                 break
+        dead = (alive[P:t] == 0).nonzero()
+        if dead.numel():
+            t = P + int(dead[0].item()) + 1
+        if scores is not None:
+            scores = [x.cpu() for x in scores[:t - P]]
         return seq[:, :t].cpu(), scores

@@ -64,7 +64,9 @@ def test_gated_activation_forward_backward(ops, dtype, act):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,Sq,Sk,hd,causal,bidir,masked", [(2, 4, 10, 10, 16, False, True, False), (3, 2, 37, 37, 64, False, True, True),
                                                                (2, 3, 9, 9, 64, True, False, False), (2, 2, 1, 14, 16, True, False, False),
-                                                               (2, 2, 7, 150, 64, False, None, True), (1, 2, 130, 130, 32, False, True, True)])
+                                                               (2, 2, 7, 150, 64, False, None, True), (1, 2, 130, 130, 32, False, True, True),
+                                                               (2, 4, 150, 150, 64, False, True, True), (2, 4, 1, 14, 64, True, False, False),
+                                                               (2, 2, 5, 5, 80, True, False, False), (1, 2, 70, 70, 128, True, False, True)])
 def test_attention_with_relative_position_bias(ops, dtype, B, H, Sq, Sk, hd, causal, bidir, masked):
     """eavqa_attention_fwd_rel / _bwd_rel against float64: encoder (bidirectional buckets), decoder (causal, one-sided buckets, incl. a cached
     step Sq = 1 < Sk), cross-attention (no bias, key mask)."""
