@@ -85,7 +85,10 @@ __device__ __forceinline__ void load_bfrag(bf16x8 (&f)[KS], const bf16_t* src, i
 // acc[f] (f = 0..3, 16 register items each) = sum_d A_tile[item 16 f + (lane & 15)][d] * bfrag[d]; only the first `nf`
 // fragments are computed (a ragged last tile: 257 = 4 x 64 + 1 ViT tokens leave 63 of 64 register items empty), the rest
 // read as zero
-template <int KS>
+// SW (hd = 64 images of the streamed forward kernel): rows on a 128-byte pitch, 16-byte chunk c of row r stored at slot c ^ (r & 6) - the
+// swizzle of the resident-K/V kernel, conflict-free for these row reads and for the transposing reads of tile_accumulate (the padded
+// 144-byte pitch showed 22 % LDS conflict cycles on the LM forward, profiles/round3_bench_cfg2_bf16_mfma.md)
+template <int KS, bool SW = false>
 __device__ __forceinline__ void tile_dot(f32x4 (&acc)[4], const char* rowmaj, const bf16x8 (&bf)[KS], int x, int g, int nf = 4) {
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -93,7 +96,8 @@ __device__ __forceinline__ void tile_dot(f32x4 (&acc)[4], const char* rowmaj, co
         if (f < nf) {
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowmaj + (16 * f + x) * Geo<KS>::PR + (32 * s + 8 * g) * 2);
+                const bf16x8 a = SW ? *reinterpret_cast<const bf16x8*>(rowmaj + (16 * f + x) * 128 + (((4 * s + g) ^ (x & 6)) << 4))
+                                    : *reinterpret_cast<const bf16x8*>(rowmaj + (16 * f + x) * Geo<KS>::PR + (32 * s + 8 * g) * 2);
                 acc[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bf[s], acc[f], 0, 0, 0);
             }
         }
@@ -112,22 +116,24 @@ __device__ __forceinline__ bf16x4 lds_tr4(const char* p) {
 // tiles.  R is the ROW-MAJOR [item][d] image: the A operand (rows = d, k = items in the permuted order of the
 // accumulator-as-B trick: items 32 s2 + 4 g .. +3 and 32 s2 + 16 + 4 g .. +3) comes out of two transposing reads, so no
 // transposed copy of the tile is ever written.
-template <int KS, int D16>
+template <int KS, int D16, bool SW = false>
 __device__ __forceinline__ void tile_accumulate(f32x4 (&out)[D16], const char* rowmaj, const f32x4 (&w)[4], int x, int g,
                                                 int nf = 4) {
     const int q = x >> 2, pp = x & 3;
+    const int sw = (4 * g + q) & 6;                     // SW: swizzle key of rows 32 s2 + 4 g + q and + 16
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         if (s2 == 1 && nf <= 2) break;                  // register items 32 .. 63 are all empty
         bf16x8 b;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { b[r] = (bf16_t)w[2 * s2][r]; b[4 + r] = (bf16_t)w[2 * s2 + 1][r]; }
-        const char* row_lo = rowmaj + (32 * s2 + 4 * g + q) * Geo<KS>::PR + 8 * pp;
-        const char* row_hi = row_lo + 16 * Geo<KS>::PR;
+        const char* row_lo = SW ? rowmaj + (32 * s2 + 4 * g + q) * 128 + 8 * (pp & 1) : rowmaj + (32 * s2 + 4 * g + q) * Geo<KS>::PR + 8 * pp;
+        const char* row_hi = row_lo + 16 * (SW ? 128 : Geo<KS>::PR);
 #pragma unroll
         for (int dm = 0; dm < D16; ++dm) {
-            const bf16x4 lo = lds_tr4(row_lo + 32 * dm);
-            const bf16x4 hi = lds_tr4(row_hi + 32 * dm);
+            const int o = SW ? (((2 * dm + (pp >> 1)) ^ sw) << 4) : 32 * dm;
+            const bf16x4 lo = lds_tr4(row_lo + o);
+            const bf16x4 hi = lds_tr4(row_hi + o);
             bf16x8 a;
 #pragma unroll
             for (int r = 0; r < 4; ++r) { a[r] = lo[r]; a[4 + r] = hi[r]; }
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
     char* Vs = smem + Geo<KS>::ROW_BYTES;
     int* valid = reinterpret_cast<int*>(Vs + Geo<KS>::ROW_BYTES);
     constexpr int QT = 16 * NW;
+    constexpr bool SW = KS == 2;                             // hd = 64: swizzled 128-byte rows (tile_dot)
 
     const int bh = blockIdx.y, b = bh / p.H, h = bh - b * p.H;
     const int q0 = blockIdx.x * QT;
@@ -214,8 +221,9 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
         for (int i = 0; i < NCH; ++i) {
             const int c = threadIdx.x + i * NT, r = c / CH, ch = c - r * CH;
             if (c < TILE * CH) {
-                *reinterpret_cast<uint4*>(Ks + r * Geo<KS>::PR + ch * 16) = kreg[i];
-                *reinterpret_cast<uint4*>(Vs + r * Geo<KS>::PR + ch * 16) = vreg[i];
+                const int o = SW ? r * 128 + ((ch ^ (r & 6)) << 4) : r * Geo<KS>::PR + ch * 16;
+                *reinterpret_cast<uint4*>(Ks + o) = kreg[i];
+                *reinterpret_cast<uint4*>(Vs + o) = vreg[i];
             }
         }
     };
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
         const int nf = min(4, (min(TILE, p.Sk - k0) + 15) >> 4);      // 16-key fragments of this tile that hold a key
         if (wave_has_query) {
         f32x4 st[4];
-        tile_dot<KS>(st, Ks, qf, x, g, nf);
+        tile_dot<KS, SW>(st, Ks, qf, x, g, nf);
         // a full tile without a mask (every tile but the last of the CLIP tower's 257 tokens): no per-key tests, and the scale moves
         // into the exponent - exp((s - m) scale) = exp2(s c - m c'), two instructions per score instead of ten
         const bool plain_tile = !p.causal && !p.key_mask && !p.rel_bias && k0 + TILE <= p.Sk && p.scale > 0.f;
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
                     lsum += pj;
                 }
         }
-        tile_accumulate<KS, D16>(acc, Vs, st, x, g, nf);
+        tile_accumulate<KS, D16, SW>(acc, Vs, st, x, g, nf);
         m = m_new;
         }
     }
