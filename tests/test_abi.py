@@ -84,13 +84,15 @@ def test_cpu_tensors_are_rejected_not_emulated():
 
 def test_decode_plans_are_pure_host_arithmetic(lib):
     """eavqa_gemm_splitk_plan / eavqa_lm_block_workspace_bytes touch no device: the split of every decode GEMM of the few-shot model
-    (OPT-2.7B, B = 32) is the one profiles/round2_decode.md was measured with, unsupported shapes give 0."""
+    (OPT-2.7B, B = 32) is the one profiles/round2_decode.md was measured with (FFN-up since round 3: 512-deep slices, no split gives one
+    workgroup per CU there), unsupported shapes give 0."""
     plan = lib.eavqa_gemm_splitk_plan
     E, F = 2560, 10240
-    assert [plan(32, 3 * E, E), plan(32, E, E), plan(32, F, E), plan(32, E, F)] == [4, 10, 4, 10]
+    assert [plan(32, 3 * E, E), plan(32, E, E), plan(32, F, E), plan(32, E, F)] == [4, 10, 5, 10]
     for M, N, K in ((32, 3 * E, E), (1, 64, 32), (64, 50272, 2560), (17, 200, 96), (64, 12800, 512)):
         ks = plan(M, N, K)
         assert ks >= 1 and K % (32 * ks) == 0 and (K // ks) * (1 if M <= 16 else 2 if M <= 32 else 4) * 32 <= 64 * 1024
+    assert plan(32, 8192, 2048) == 4 and plan(32, 16384, 4096) == 8        # OPT-1.3B FFN-up: one round exists; OPT-6.7B: 512-deep slices
     assert plan(65, 128, 64) == 0 and plan(8, 128, 48) == 0 and plan(0, 128, 64) == 0
     ws = lib.eavqa_lm_block_workspace_bytes
     small, big = ws(1, 32, E, F), ws(1, 4800, E, F)             # dtype 1 = bfloat16: a decode step, the 150-position prefill of 32 prompts

@@ -176,6 +176,40 @@ def test_vct0_generate_paths_match_reference_ids(tag):
     assert (torch.stack(list(o.scores))[:1] - want[:1]).abs().max().item() <= 8e-2 * max(1.0, want.abs().max().item())     # first step: same decoder prefix
 
 
+@pytest.mark.parametrize("tag", ["t0", "t5v10"])
+def test_vct0_generate_stops_early_like_hf_greedy(tag):
+    """Rows that emit eos continue with pad and the search stops as soon as every row has finished (HF greedy search; the fixtures' random-init
+    models never emit T5's eos, so eos is moved onto tokens they do emit).  The HIP loop looks at the finished flags every fourth step
+    only and trims afterwards: sequences, their length and the number of score steps must equal the oracle's step-by-step search."""
+    z, T, model, V = _model(tag, torch.float32)
+    model.eval()
+    sd = {k[3:]: T(v) for k, v in z.items() if k.startswith("lm.")}
+    V_, E, DKV, H, F, NL, L, D, gated, tied = [int(v) for v in z["cfg"]]
+    mapper = {k[4:]: T(v) for k, v in z.items() if k.startswith("map.")}
+    base = model.generate(prefix=T(z["fs_prefix"]), question_tokens=T(z["fs_tokens"]), question_mask=T(z["fs_mask"]), special_token_id=V - 1, max_length=12)
+    first = base[:, 1].tolist()
+    stopped_early = 0
+    # (eos, rows): the whole batch with every emitted token as eos (some rows finish, the search goes on) and one never emitted; then only
+    # the rows that emit token e, with eos = e: every row finishes at the first step and the search stops there
+    cases = [(e, list(range(len(first)))) for e in sorted(set(first)) + [V - 2]] + [(e, [i for i, f in enumerate(first) if f == e]) for e in sorted(set(first))]
+    for eos, rows in cases:
+        model.lm.cfg.eos_token_id = eos
+        pf, tk, mk = T(z["fs_prefix"])[rows], T(z["fs_tokens"])[rows], T(z["fs_mask"])[rows]
+        got = model.generate(prefix=pf, question_tokens=tk, question_mask=mk, special_token_id=V - 1, max_length=12, output_scores=True,
+                             return_dict_in_generate=True)
+        ocfg = dict(n_layer=NL, n_head=H, d_kv=DKV, gated=bool(gated), tied=bool(tied), eos_token_id=eos)
+        with torch.no_grad():
+            want, want_scores = oracle.vct0_generate(sd, ocfg, mapper, dict(prefix_length=L, mapping_type="mlp"), pf, tk, mk, max_length=12,
+                                                     special_token_id=V - 1)
+        assert got.sequences.shape == want.shape and len(got.scores) == len(want_scores), (eos, rows, got.sequences.shape, want.shape)
+        top2 = torch.stack(want_scores).topk(2, dim=-1).values
+        if ((top2[..., 0] - top2[..., 1]) > 1e-3).all().item():
+            assert torch.equal(got.sequences, want), (eos, rows, got.sequences, want)
+        stopped_early += int(want.shape[1] < 12)
+    model.lm.cfg.eos_token_id = 1
+    assert stopped_early >= 1                            # the case this test exists for did occur
+
+
 def test_vct0_prefix_trains_only_the_mapper_and_decoder_prompt_path():
     z, T, model, V = _model("t0", torch.float32)
     names = {n for n, _ in model.clip_project.named_parameters()}
