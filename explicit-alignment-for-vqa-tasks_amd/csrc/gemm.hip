@@ -29,8 +29,10 @@ struct Knobs {
     int deep;           // [17:16] 2 = force the 8-stage ring of the round-1 128 x 128 kernel (experiment)
     int shape_mode;     // [20:18] round-1 shaped tiles: 0 by cost model, 1 never, 2.. force SHAPES[id - 2]
     int group_n;        // [24:21] 256 x 256 kernel, tile order inside an XCD: 0 = library default, 1 = m fastest (round 2), 2.. = groups of (value - 1) columns
+    bool no_row_split;  // [25]    256 x 256 kernel: keep a ragged last tile row in the same launch (A / B of big_split_rows)
     explicit Knobs(int k = 0) : stagger(k & 15), ablate((k >> 4) & 7), disable_fast(((k >> 7) & 1) != 0), k64_mode((k >> 8) & 63),
-                                big_mode((k >> 14) & 3), deep((k >> 16) & 3), shape_mode((k >> 18) & 7), group_n((k >> 21) & 15) {}
+                                big_mode((k >> 14) & 3), deep((k >> 16) & 3), shape_mode((k >> 18) & 7), group_n((k >> 21) & 15),
+                                no_row_split(((k >> 25) & 1) != 0) {}
 };
 
 struct GemmParams {
@@ -931,6 +933,19 @@ __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int g
     }
 }
 
+// XCD rectangle of the 256 x 256 kernel: gx x gy XCDs over tile rows x tile columns with the fewest panels per XCD; returns tiles per XCD
+inline int big_grid(int tiles_m, int tiles_n, int& gx, int& gy) {
+    int best_gx = 8, best_cost = 1 << 30;
+    const int cand[4] = {8, 4, 2, 1};
+    for (int c = 0; c < 4; ++c) {
+        const int x = cand[c], y = 8 / x;
+        const int cost = (tiles_m + x - 1) / x + (tiles_n + y - 1) / y;
+        if (cost < best_cost) { best_cost = cost; best_gx = x; }
+    }
+    gx = best_gx; gy = 8 / gx;
+    return ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
+}
+
 int launch_big(const GemmParams& p, hipStream_t stream) {
     static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
     if (!configured.load(std::memory_order_acquire)) {
@@ -940,18 +955,24 @@ int launch_big(const GemmParams& p, hipStream_t stream) {
         configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + GBM - 1) / GBM, tiles_n = (p.N + GBN - 1) / GBN;
-    int best_gx = 8, best_cost = 1 << 30;
-    const int cand[4] = {8, 4, 2, 1};
-    for (int c = 0; c < 4; ++c) {
-        const int gx = cand[c], gy = 8 / gx;
-        const int cost = (tiles_m + gx - 1) / gx + (tiles_n + gy - 1) / gy;
-        if (cost < best_cost) { best_cost = cost; best_gx = gx; }
-    }
-    const int gx = best_gx, gy = 8 / gx;
-    const int per_xcd = ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
+    int gx, gy;
+    const int per_xcd = big_grid(tiles_m, tiles_n, gx, gy);
     hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3(per_xcd * 8), dim3(1024), GLDS_BYTES, stream, p, gx, gy, tiles_m, tiles_n);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
+}
+
+// Rows to hand to a second, small-tile launch (0 = none): when the last tile row is ragged (M % 256 <= 192 rows) and the problem without it
+// needs one round of workgroups less.  The CLIP tower at 64 images is M = 16 448 = 64 tile rows + 64 rows: out-proj / FFN-down are 260
+// tiles = TWO rounds for 256 CUs (the second one of four tiles), QKV 780 = four rounds instead of three; at 160 images FFN-up is 2 576
+// tiles = eleven rounds instead of ten.  Every tile costs the same whatever its valid rows, so the few ragged rows cost a whole round.
+inline int big_split_rows(int M, int N) {
+    const int rem = M % GBM;
+    if (rem == 0 || rem > 192 || M <= GBM) return 0;
+    int gx, gy;
+    const int tiles_n = (N + GBN - 1) / GBN;
+    const int with = (big_grid((M + GBM - 1) / GBM, tiles_n, gx, gy) + 31) / 32, without = (big_grid(M / GBM, tiles_n, gx, gy) + 31) / 32;
+    return without < with ? rem : 0;
 }
 
 bool use_big(const GemmParams& p, const Knobs& kn) {
@@ -1264,7 +1285,27 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
         // keep the round-1 dispatcher below, calibrated on exactly those shapes; 2-3 rounds at moderate M (few-shot prefill, M = 4 800)
         // are ranked here, where round quantisation decides: 570 tiles are 3 rounds of the 256 x 256 kernel but 3.6 of 256 x 160
         // (measured 177 against 215 us on the QKV projection; the grid of tools/dispatch_calib.py is the evidence for both limits).
-        const GridPlan gbig = plan_grid((M + GBM - 1) / GBM, (N + GBN - 1) / GBN, GBM, GBN);
+        // ragged last tile row handed to a second launch when that saves a round (big_split_rows): the costs below count the rounds of the
+        // full tile rows plus ~12 us for the second launch
+        const int big_rem = (a_kc && b_kc && kn.big_mode != 1 && !kn.no_row_split) ? big_split_rows(M, N) : 0;
+        const float big_split_ns = big_rem ? 12000.f : 0.f;
+        auto run_big = [&](const GemmParams& pp) -> int {
+            if (!big_rem) return launch_big(pp, s);
+            GemmParams p1 = pp;
+            p1.M = M - big_rem;
+            p1.tiles_m = (p1.M + BM - 1) / BM;
+            const int rc1 = launch_big(p1, s);
+            if (rc1) return rc1;
+            const int64_t r0 = M - big_rem;
+            const size_t ces = out_f32 ? 4 : 2, res_es = res_lowp ? 2 : 4;
+            auto off = [](const void* base, int64_t rows, int64_t ld, size_t es) -> const void* {
+                return base ? static_cast<const char*>(base) + (size_t)rows * (size_t)ld * es : nullptr;
+            };
+            return eavqa_gemm_ex(dtype, a_kc, b_kc, big_rem, N, K, off(A, r0, lda, 2), lda, B, ldb, const_cast<void*>(off(C, r0, ldc, ces)), ldc, out_flags,
+                                 alpha, bias, act, off(aux_in, r0, ld_aux, 2), const_cast<void*>(off(aux_out, r0, ld_aux, 2)), ld_aux,
+                                 off(residual, r0, ldr, res_es), ldr, stream, 0);
+        };
+        const GridPlan gbig = plan_grid((M - big_rem + GBM - 1) / GBM, (N + GBN - 1) / GBN, GBM, GBN);
         const int big_rounds = (gbig.per_xcd + 31) / 32;
         const bool many_big_tiles = big_rounds >= 4 || (big_rounds >= 2 && (M + GBM - 1) / GBM > 96);
         if (a_kc && b_kc && !kn.disable_fast && (K % 64) == 0 && kn.k64_mode != 1 && kn.shape_mode == 0 && kn.big_mode == 0 && !many_big_tiles) {
@@ -1283,25 +1324,30 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
             // round-1 256 x 256 kernel: 2.99 ns per 128-byte row and 64-deep K-step of its 512 rows, ~6 us fixed (square 4k / fc1 fwd);
             // the same multi-round charge (3 rounds on the prefill QKV shape: 215 us measured against 190 modelled)
             const float big_loop = float(big_rounds) * 2.99f * 512.f * (K / 64);
-            const float big_cost = big_loop * (big_rounds > 1 ? 1.35f : 1.f) + 6000.f;
-            if (M > 64 && big_cost < best) return launch_big(p, s);
+            const float big_cost = big_loop * (big_rounds > 1 ? 1.35f : 1.f) + 6000.f + big_split_ns;
+            if (M > 64 && big_cost < best) return run_big(p);
             return K64_SHAPES[pick].launch(p, s);
         }
         if (a_kc && b_kc && !kn.disable_fast && (K % FBK) == 0) {
             if (kn.shape_mode >= 2 && kn.shape_mode < 7) return SHAPES[kn.shape_mode - 2].launch(p, s);
             const bool big_ok = (K % GBK) == 0 && kn.big_mode != 1;
-            if (big_ok && kn.big_mode == 2) return launch_big(p, s);
+            if (big_ok && kn.big_mode == 2) return run_big(p);
             // candidates in order of preference at equal cost: 128 x 128 (two workgroups per CU), 256 x 256, shaped tiles
             float best = tile_cost(p, 128, 128, RATE_FAST);
             int pick = -1;                                   // -1 fast, -2 big, >= 0 SHAPES[pick]
-            if (big_ok && use_big(p, kn)) { best = fminf(best, tile_cost(p, 256, 256, RATE_BIG)); pick = -2; }
+            if (big_ok && use_big(p, kn)) {
+                GemmParams pf = p;
+                pf.M = M - big_rem;
+                best = fminf(best, tile_cost(pf, 256, 256, RATE_BIG) + big_split_ns);
+                pick = -2;
+            }
             if (kn.shape_mode != 1)
                 for (int i = 0; i < 5; ++i) {
                     const float c = tile_cost(p, SHAPES[i].bm, SHAPES[i].bn, SHAPES[i].rate);
                     if (c < best * 0.95f) { best = c; pick = i; }
                 }
             if (pick >= 0) return SHAPES[pick].launch(p, s);
-            if (pick == -2) return launch_big(p, s);
+            if (pick == -2) return run_big(p);
             return launch_fast(p, s, kn);
         }
         if (a_kc && b_kc) return launch(gemm_bf16_kernel<true, true>, p, s);

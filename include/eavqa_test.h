@@ -23,7 +23,9 @@ extern "C" {
  *   [15:14] round-1 256 x 256 kernel: 0 by shape, 1 never, 2 always (K % 64 == 0)
  *   [17:16] 2 = 8-stage LDS ring of the round-1 128 x 128 kernel (experiment)
  *   [20:18] round-1 shaped tiles: 0 by cost model, 1 never, 2..6 always 128x80 / 128x96 / 256x128 / 256x160 / 256x192
- *   [24:21] 256 x 256 kernel, order of an XCD's tiles in time: 0 library default, 1 m fastest (round 2), 2..15 column groups of value - 1 */
+ *   [24:21] 256 x 256 kernel, order of an XCD's tiles in time: 0 library default, 1 m fastest (round 2), 2..15 column groups of value - 1
+ *   [25]    256 x 256 kernel: 1 keeps a ragged last tile row in the same launch (default: M % 256 <= 192 rows go to a second, small-tile
+ *           launch when that saves a round of workgroups) */
 int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                   const void* A, int64_t lda, const void* B, int64_t ldb,
                   void* C, int64_t ldc, int out_flags, float alpha,

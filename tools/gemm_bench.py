@@ -50,13 +50,14 @@ def main():
     ap.add_argument("--group-n", type=int, default=0, help="256 x 256 kernel tile order: 0 default, 1 m fastest, 2.. column groups of value - 1")
     ap.add_argument("--epi", default="", help="epilogue of the timed call: '' plain bf16 out | 'fc1' bias + gelu_new + aux_out | 'quick' bias + quick_gelu | "
                                               "'res32' bias + fp32 residual in place | 'res16' bias + half residual in place | 'bwd' gelu_new derivative at aux_in")
+    ap.add_argument("--no-split", action="store_true", help="256 x 256 kernel: keep a ragged last tile row in the same launch")
     ap.add_argument("--deep", type=int, default=0, help="8-stage ring: 0 auto, 1 never, 2 always")
     ap.add_argument("--check", action="store_true", help="compare the result with a torch matmul")
     ap.add_argument("--cold", action="store_true", help="rotate over enough copies of the weight to defeat L2 + Infinity Cache")
     ap.add_argument("--only", default="", help="comma-separated substrings of the shape names to run")
     args = ap.parse_args()
     ops.KernelSelect.gemm = (args.stagger | (args.ablate << 4) | (int(args.general) << 7) | (args.k64 << 8) | (args.big << 14) | (args.deep << 16)
-                             | (args.shape << 18) | (args.group_n << 21))
+                             | (args.shape << 18) | (args.group_n << 21) | (int(args.no_split) << 25))
     dev = "cuda"
     only = [w for w in args.only.split(",") if w]
     for M, N, K, what in SHAPES:
