@@ -934,13 +934,16 @@ __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int g
 }
 
 // XCD rectangle of the 256 x 256 kernel: gx x gy XCDs over tile rows x tile columns with the fewest panels per XCD; returns tiles per XCD
+// (round 3: fewest ROUNDS of 32 workgroups per XCD first - the few-shot prefill's FFN-up, 19 x 40 tiles, is 10 x 10 = 100 tiles per XCD =
+// four rounds on the 2 x 4 rectangle with the fewest panels but 19 x 5 = 95 = three rounds on 1 x 8 - then the fewest panels)
 inline int big_grid(int tiles_m, int tiles_n, int& gx, int& gy) {
-    int best_gx = 8, best_cost = 1 << 30;
+    int best_gx = 8, best_cost = 1 << 30, best_rounds = 1 << 30;
     const int cand[4] = {8, 4, 2, 1};
     for (int c = 0; c < 4; ++c) {
         const int x = cand[c], y = 8 / x;
-        const int cost = (tiles_m + x - 1) / x + (tiles_n + y - 1) / y;
-        if (cost < best_cost) { best_cost = cost; best_gx = x; }
+        const int pm = (tiles_m + x - 1) / x, pn = (tiles_n + y - 1) / y;
+        const int rounds = (pm * pn + 31) / 32, cost = pm + pn;
+        if (rounds < best_rounds || (rounds == best_rounds && cost < best_cost)) { best_rounds = rounds; best_cost = cost; best_gx = x; }
     }
     gx = best_gx; gy = 8 / gx;
     return ((tiles_m + gx - 1) / gx) * ((tiles_n + gy - 1) / gy);
@@ -1305,8 +1308,8 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                                  alpha, bias, act, off(aux_in, r0, ld_aux, 2), const_cast<void*>(off(aux_out, r0, ld_aux, 2)), ld_aux,
                                  off(residual, r0, ldr, res_es), ldr, stream, 0);
         };
-        const GridPlan gbig = plan_grid((M - big_rem + GBM - 1) / GBM, (N + GBN - 1) / GBN, GBM, GBN);
-        const int big_rounds = (gbig.per_xcd + 31) / 32;
+        int bgx, bgy;
+        const int big_rounds = (big_grid((M - big_rem + GBM - 1) / GBM, (N + GBN - 1) / GBN, bgx, bgy) + 31) / 32;      // the rounds launch_big runs
         const bool many_big_tiles = big_rounds >= 4 || (big_rounds >= 2 && (M + GBM - 1) / GBM > 96);
         if (a_kc && b_kc && !kn.disable_fast && (K % 64) == 0 && kn.k64_mode != 1 && kn.shape_mode == 0 && kn.big_mode == 0 && !many_big_tiles) {
             int pick = K64_AUTO[0];
@@ -1321,10 +1324,11 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
             // larger problem that re-reads its panels from the Infinity Cache / HBM: measured 1.3-1.4x slower than the model (few-shot
             // prefill: out-proj 90.8 us against 72.1 us, FFN-down 313 against 244 us on the 256 x 256 kernel) - charge it before comparing
             best += 0.35f * best_loop;
-            // round-1 256 x 256 kernel: 2.99 ns per 128-byte row and 64-deep K-step of its 512 rows, ~6 us fixed (square 4k / fc1 fwd);
-            // the same multi-round charge (3 rounds on the prefill QKV shape: 215 us measured against 190 modelled)
-            const float big_loop = float(big_rounds) * 2.99f * 512.f * (K / 64);
-            const float big_cost = big_loop * (big_rounds > 1 ? 1.35f : 1.f) + 6000.f + big_split_ns;
+            // 256 x 256 kernel, re-fitted in round 3 on the rounds it really runs (big_grid): per round of workgroups 1.53 us per 64-deep K-tile
+            // (1.38 when the whole problem is one round: panels stay in L2) + 9 us outside the K loop (first tile's round trip, C pass),
+            // 3 us launch.  Fits vitL QKV / out-proj / FFN-up / FFN-down 271 / 103 / 350 / 324 against 270 / 101 / 340 / 324 us measured,
+            // prefill QKV / FFN-up 214 / 214 against 191 / 203, OPT-6.7B FFN-up 217 against 211, 8192^3 822 against 851.
+            const float big_cost = float(big_rounds) * (float(K / 64) * (big_rounds == 1 ? 1380.f : 1530.f) + 9000.f) + 3000.f + big_split_ns;
             if (M > 64 && big_cost < best) return run_big(p);
             return K64_SHAPES[pick].launch(p, s);
         }
