@@ -430,6 +430,12 @@ def main():
                     help="write the algorithmic bytes per launch of the HBM-bound ops of one step as JSON (input of tools/round_profile_report.py)")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON: whatever libraries print there meanwhile (gloo's "[Gloo] Rank 0 is connected ...", RCCL / HIP
+    # notices) is sent to stderr - file descriptor 1 points at stderr until the line is written
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from eavqa_amd import _lib
     from eavqa_amd.trainers.data_parallel import init_from_env
 
@@ -474,10 +480,12 @@ def main():
     if rank == 0:
         line["cpu_baseline"] = cpu
         line["extra"] = extra or None
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    os.close(json_fd)
 
 
 def gemm_source_digest():

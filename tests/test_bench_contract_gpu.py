@@ -14,8 +14,8 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-baseline-samples", "8"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # stdout is the JSON line and nothing else
     d = json.loads(lines[0])
     baseline = json.load(open(os.path.join(ROOT, "BASELINE.json")))
     assert "train samples/sec" in baseline["metric"]                      # the half of BASELINE.json's metric this line carries
@@ -53,3 +53,25 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
         assert e["value"] > 0 and r3["gemm_ms_per_step"] <= e["ms_per_step"], (e["config"]["workload"], r3["gemm_ms_per_step"], e["ms_per_step"])
         assert abs(r3["frac"] - r3["achieved"] / r3["peak"]) < 1e-3 and r3["peak"] == (5000.0 if e["dtype"] == "fp8" else 2500.0)
         assert r3["vit_tower_gemms"]["gemm_ms_per_step"] > 0
+
+
+def test_bench_two_ranks_rehearsal_prints_one_line_with_the_exchange_fields():
+    """The N > 1 control flow of bench.py end to end - launched as the driver launches it (torch.distributed.run, one process per rank) - on
+    this one-GPU box: both ranks on the card, gloo instead of RCCL (RCCL refuses two ranks on one device).  The numbers mean nothing; the
+    line must be the only thing on stdout (gloo prints a connection notice there) and carry the distributed fields."""
+    env = dict(os.environ, EAVQA_DIST_BACKEND="gloo", EAVQA_FORCE_DEVICE="0")
+    for exchange in ("auto", "sharded"):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                            "--cpu-baseline-samples", "0", "--no-roofline", "--dp-exchange", exchange],
+                           capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.strip()]
+        assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+        d = json.loads(lines[0])
+        c = d["config"]
+        assert d["n_gpus"] == 2 and c["global_batch"] == 128 and c["parallelism"] == "dp2" and c["world_size"] == 2 and c["backend"] == "gloo"
+        assert set(c["dp_exchange_model_ms_unmeasured"]) == {"allreduce", "sharded", "factors"}
+        assert c["dp_exchange"].startswith("mapper gradient factors" if exchange == "auto" else "reduce-scatter")
+        assert d["extra"] is None and d["cpu_baseline"] is None and d["value"] > 0           # secondary legs belong to the N = 1 run
+        assert abs(d["value"] - 128 / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
