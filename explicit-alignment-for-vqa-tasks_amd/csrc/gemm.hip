@@ -1280,7 +1280,11 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
         if (a_kc && b_kc && (K % 64) == 0 && kn.k64_mode >= 2 && kn.k64_mode < 2 + N_K64) return K64_SHAPES[kn.k64_mode - 2].launch(p, s);
-        if (a_kc && b_kc && !kn.disable_fast && M <= 64 && (K % 32) == 0 && N >= 64 && (kn.k64_mode == 1 || (K % 64) != 0)) return launch_skinny(p, s);
+        // M <= 64 with few columns (T5 decoder passes at one or two tokens: N = 2048 is 26 tiles of 128 x 80 for 256 CUs): the 16-column
+        // weight-streaming kernel has N / 16 workgroups - 8.7 against 15.1 us at N = K = 2048, 20.9 against 31.9 us at K = 5120 (cold
+        // weights); from N = 6144 on the tiles win again (16.6 against 22.3 us at N = 10240)
+        const bool few_columns = kn.k64_mode == 0 && kn.shape_mode == 0 && kn.big_mode == 0 && N <= 4096;
+        if (a_kc && b_kc && !kn.disable_fast && M <= 64 && (K % 32) == 0 && N >= 64 && (kn.k64_mode == 1 || (K % 64) != 0 || few_columns)) return launch_skinny(p, s);
         // Default dispatch (K % 64 == 0): the loader / consumer specialised full-line tile the cost model ranks first, or the
         // round-1 256 x 256 kernel where the model says its 1/128 B-per-FLOP intensity wins (problems with hundreds of such tiles:
         // the CLIP tower, few-shot prefill, lm_head forward).  M <= 64 weight-streaming shapes take the same route.

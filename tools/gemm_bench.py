@@ -33,6 +33,9 @@ SHAPES = [  # (M, N, K, what)
     (4800, 7680, 2560, "prefill qkv"), (4800, 2560, 2560, "prefill proj"), (4800, 10240, 2560, "prefill fc1"), (4800, 2560, 10240, "prefill fc2"),
     (41120, 4096, 64, "kslope 64"), (41120, 4096, 256, "kslope 256"), (41120, 4096, 512, "kslope 512"), (41120, 4096, 2048, "kslope 2048"),
     (41120, 4096, 4096, "kslope 4096"), (41120, 4096, 4160, "kslope 4160 (odd pitch)"), (41120, 4096, 1088, "kslope 1088 (odd pitch)"), (41120, 4096, 1024, "kslope 1024"), (40960, 4096, 1024, "kslope full tiles 1024"), (8192, 8192, 1024, "one round 1024"), (8192, 8192, 4096, "one round 4096"),
+    (32, 6144, 2048, "t5dec qkv"), (32, 2048, 2048, "t5dec o"), (32, 10240, 2048, "t5dec wi"), (32, 2048, 5120, "t5dec wo"),
+    (160, 6144, 2048, "t5dec5 qkv"), (160, 2048, 2048, "t5dec5 o"), (160, 10240, 2048, "t5dec5 wi"), (160, 2048, 5120, "t5dec5 wo"),
+    (288, 2048, 2048, "t5dec9 o"), (288, 2048, 5120, "t5dec9 wo"),
     (3200, 3072, 768, "vit fc1"), (3200, 768, 3072, "vit fc2"), (4096, 4096, 4096, "square 4k"), (8192, 8192, 8192, "square 8k"),
 ]
 
