@@ -264,6 +264,33 @@ class FrozenT5:
         out, rf = ops.rmsnorm_fwd(x, self.dec_final, c.eps, T, save_stats=True)
         return out, (dict(layers=tape, x_last=x, rf=rf, enc_mask=enc_mask, B=B, Td=Td, S=S) if save else None)
 
+    def decode_step(self, y_last: Tensor, cache: List, enc_mask: Tensor, B: int, t: int, S: int, kv: List[Tensor], t_max: int) -> Tensor:
+        """One cached decoder step: ``y_last`` float32 [B, E] is the input embedding of decoder position t - 1; the self-attention K / V of
+        positions 0 .. t - 2 are in ``cache`` (per layer two [B * t_max, inner] row views), position t - 1 is appended here.  Same
+        arithmetic as the last row of :meth:`decode` over t positions (one query at the END of t keys: causal offset and relative-position
+        bias as there), on B rows instead of B * t - which keeps every GEMM on the M <= 64 weight-streaming kernels.  Returns [B, E]."""
+        c, T = self.cfg, self.dtype
+        I, H, dkv = c.inner, c.n_head, c.d_kv
+        rel, zero = self.rel_table(True, t)
+        x = y_last
+        for li, b in enumerate(self.dec):
+            a = ops.rmsnorm_fwd(x, b.ln_sa, c.eps, T)
+            qkv = ops.gemm(a, b.w_qkv)
+            kc, vc = cache[li]
+            ops.copy_rows(qkv[:, I:2 * I], kc, B, 1, I, 1, t_max, t - 1)
+            ops.copy_rows(qkv[:, 2 * I:], vc, B, 1, I, 1, t_max, t - 1)
+            ctx = ops.attention_fwd_rel(qkv[:, :I], kc, vc, B, H, 1, t, dkv, rel_bias=rel, rel_zero=zero, causal=True, scale=1.0,
+                                        q_batch_rows=1, kv_batch_rows=t_max)
+            x1 = ops.gemm(ctx, b.w_o, residual=x, out_f32=True)
+            ac = ops.rmsnorm_fwd(x1, b.ln_ca, c.eps, T)
+            qc = ops.gemm(ac, b.w_q_ca)
+            kvc = kv[li]
+            cctx = ops.attention_fwd_rel(qc, kvc[:, :I], kvc[:, I:], B, H, 1, S, dkv, rel_bias=None, key_mask=enc_mask, causal=False, scale=1.0)
+            x2 = ops.gemm(cctx, b.w_o_ca, residual=x1, out_f32=True)
+            a3 = ops.rmsnorm_fwd(x2, b.ln_ff, c.eps, T)
+            x, _ = self._ffn(b, a3, x2, False)
+        return ops.rmsnorm_fwd(x, self.dec_final, c.eps, T)
+
     def logits(self, hidden: Tensor) -> Tensor:
         lg = torch.empty((hidden.shape[0], self.vpad), device=self.device, dtype=torch.float32)
         ops.gemm(hidden, self.head, out=lg[:, :self.cfg.vocab], alpha=self.head_alpha)
@@ -358,10 +385,11 @@ class FrozenT5:
     # ---------------------------------------------------------------- greedy generation
     @torch.no_grad()
     def greedy(self, enc_out: Tensor, enc_mask: Tensor, B: int, S: int, max_length: int, dec_prompt: Optional[Tensor] = None,
-               output_scores: bool = False):
+               output_scores: bool = False, use_cache: bool = True):
         """HF greedy search for an encoder-decoder: start = decoder_start_token_id, a row that produced eos emits pad afterwards, stop
         when every row is finished or ``max_length`` decoder positions exist.  The cross-attention K / V of every layer are computed
-        once; every step re-runs the decoder over its (short) own prefix - the logits of the cached run.  Returns
+        once; a step runs the decoder on the newest position against a self-attention K / V cache (``use_cache``; with a multi-token
+        decoder prompt, or ``use_cache=False``, every step re-runs the decoder over its own short prefix - the same logits).  Returns
         ``(sequences int64 [B, <= max_length] on the host, [per-step logits float32 [B, V] on the host] | None)``."""
         c = self.cfg
         kv = self.cross_kv(enc_out)
@@ -376,11 +404,19 @@ class FrozenT5:
         # device -> host round trip per step would keep the launch queue empty); positions written after every row had finished hold
         # pad and are cut off below, so the result is the one of a check after every step.
         alive = torch.ones(max(max_length, P) + 1, dtype=torch.int32, device=self.device)
+        cached = use_cache and P == 1 and max_length > 1
+        if cached:
+            t_max = max_length
+            cache = [(torch.empty((B * t_max, c.inner), device=self.device, dtype=self.dtype),
+                      torch.empty((B * t_max, c.inner), device=self.device, dtype=self.dtype)) for _ in self.dec]
         t = P
         while t < max_length:
-            y = self.embed(seq[:, :t].contiguous())
-            hid, _ = self.decode(y, enc_out, enc_mask, B, t, S, kv=kv)
-            last = hid.view(B, t, c.d_model)[:, -1].contiguous()
+            if cached:
+                last = self.decode_step(self.embed(seq[:, t - 1].contiguous()), cache, enc_mask, B, t, S, kv, t_max)
+            else:
+                y = self.embed(seq[:, :t].contiguous())
+                hid, _ = self.decode(y, enc_out, enc_mask, B, t, S, kv=kv)
+                last = hid.view(B, t, c.d_model)[:, -1].contiguous()
             lg = self.logits(last)
             if output_scores:
                 scores.append(lg[:, :c.vocab].float())

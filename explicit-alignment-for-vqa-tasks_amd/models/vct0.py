@@ -134,9 +134,9 @@ class VCT0Model(nn.Module):
                  decoder_input_ids: Optional[Tensor] = None, decoder_attention_mask: Optional[Tensor] = None, no_prefix: Optional[bool] = False,
                  pass_examples_through_encoder_one_at_a_time: Optional[bool] = False, num_shots: Optional[int] = None,
                  special_token_id: int = 32099, max_length: int = 20, output_scores: bool = False, return_dict_in_generate: bool = False,
-                 **generation_kwargs):
+                 use_cache: bool = True, **generation_kwargs):
         """Greedy generation (HF defaults of ``lm.generate``; ``max_length`` counts the decoder start token).  ``special_token_id`` is an
-        addition: the reference hard-codes T5's 32099."""
+        addition: the reference hard-codes T5's 32099; ``use_cache`` (HF's name and default): decoder steps against a self-attention K / V cache.  """
         dev, lm, L = self.device_, self.lm, self.prefix_length
         unsupported = {k: v for k, v in generation_kwargs.items() if k not in ("bos_token_id", "do_sample", "num_beams") or (k == "num_beams" and v != 1)
                        or (k == "do_sample" and v)}
@@ -152,14 +152,14 @@ class VCT0Model(nn.Module):
                 raise NotImplementedError("text-only generation one example at a time (vct0.py:411-419) is not built")
             B, T = tok.shape
             enc, _ = lm.encode(lm.embed(tok), qm.to(torch.int32).contiguous(), B, T)
-            return finish(*lm.greedy(enc, qm.to(torch.int32).contiguous(), B, T, max_length, output_scores=output_scores))
+            return finish(*lm.greedy(enc, qm.to(torch.int32).contiguous(), B, T, max_length, output_scores=output_scores, use_cache=use_cache))
         if tok is None:                                                    # prefix only (:485-491)
             rows = self._project(prefix)
             B = rows.shape[0] // L
             mask = torch.ones((B, L), device=dev, dtype=torch.int32)
             src = -(torch.arange(B * L, device=dev, dtype=torch.int32) + 1)
             enc, _ = lm.encode(ops.embed_assemble(src, None, lm.shared, rows, None), mask, B, L)
-            return finish(*lm.greedy(enc, mask, B, L, max_length, output_scores=output_scores))
+            return finish(*lm.greedy(enc, mask, B, L, max_length, output_scores=output_scores, use_cache=use_cache))
         B = tok.shape[0]
         prefix = prefix.to(dev).reshape(B, -1, prefix.shape[-1])
         n_img = prefix.shape[1]
@@ -176,14 +176,14 @@ class VCT0Model(nn.Module):
             enc = torch.cat(encs, dim=1)
             mask = torch.cat(masks, dim=1).contiguous()
             S = enc.shape[1]
-            return finish(*lm.greedy(enc.reshape(B * S, E).contiguous(), mask, B, S, max_length, output_scores=output_scores))
+            return finish(*lm.greedy(enc.reshape(B * S, E).contiguous(), mask, B, S, max_length, output_scores=output_scores, use_cache=use_cache))
         if decoder_input_ids is not None:                                  # :468-480: only the query image, the decoder continues a prompt
             enc, mask, S = self._encode_interleaved(tok, qm, rows.view(B, n_img, L, -1)[:, -1].reshape(B * L, -1).contiguous(), 1, special_token_id)
-            seq, scores = lm.greedy(enc, mask, B, S, max_length, dec_prompt=decoder_input_ids, output_scores=output_scores)
+            seq, scores = lm.greedy(enc, mask, B, S, max_length, dec_prompt=decoder_input_ids, output_scores=output_scores, use_cache=use_cache)
             return finish(seq[:, decoder_input_ids.shape[1]:], scores)
         ns = (n_img - 1) if not num_shots else num_shots
         enc, mask, S = self._encode_interleaved(tok, qm, rows, ns + 1, special_token_id)
-        return finish(*lm.greedy(enc, mask, B, S, max_length, output_scores=output_scores))
+        return finish(*lm.greedy(enc, mask, B, S, max_length, output_scores=output_scores, use_cache=use_cache))
 
 
 class VCT0Prefix(VCT0Model):

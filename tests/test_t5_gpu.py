@@ -176,6 +176,26 @@ def test_vct0_generate_paths_match_reference_ids(tag):
     assert (torch.stack(list(o.scores))[:1] - want[:1]).abs().max().item() <= 8e-2 * max(1.0, want.abs().max().item())     # first step: same decoder prefix
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-2)])
+def test_vct0_cached_decoder_steps_equal_the_reforward_loop(dtype, tol):
+    """``use_cache=True`` (one query against the self-attention K / V cache, B rows per step) against ``use_cache=False`` (the decoder re-run
+    over its whole prefix every step, as the oracle and HF without a cache do): per-step scores equal within the arithmetic's rounding, ids
+    equal in fp32."""
+    z, T, model, V = _model("t0", dtype)
+    model.eval()
+    kw = dict(prefix=T(z["fs_prefix"]), question_tokens=T(z["fs_tokens"]), question_mask=T(z["fs_mask"]), special_token_id=V - 1, max_length=9,
+              output_scores=True, return_dict_in_generate=True)
+    a, b = model.generate(use_cache=True, **kw), model.generate(use_cache=False, **kw)
+    sa, sb = torch.stack(list(a.scores)), torch.stack(list(b.scores))
+    assert sa.shape == sb.shape
+    if dtype == torch.float32:
+        assert (sa - sb).abs().max().item() <= tol * max(1.0, sb.abs().max().item())
+        assert torch.equal(a.sequences, b.sequences)
+    else:
+        assert (sa[:1] - sb[:1]).abs().max().item() <= tol * max(1.0, sb.abs().max().item())      # first step: same decoder prefix in both
+        assert a.sequences.shape == b.sequences.shape
+
+
 @pytest.mark.parametrize("tag", ["t0", "t5v10"])
 def test_vct0_generate_stops_early_like_hf_greedy(tag):
     """Rows that emit eos continue with pad and the search stops as soon as every row has finished (HF greedy search; the fixtures' random-init
