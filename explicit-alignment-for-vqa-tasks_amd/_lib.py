@@ -72,6 +72,15 @@ class LMLayer(C.Structure):
                                           "w_fc2", "b_fc2", "k_cache", "v_cache")]
 
 
+class T5DecLayer(C.Structure):
+    """``eavqa_t5_dec_layer_t``."""
+    _fields_ = [(n, C.c_void_p) for n in ("ln_sa", "w_qkv", "w_o", "ln_ca", "w_q_ca", "w_o_ca", "ln_ff", "w_i", "w_o_ff", "k_cache", "v_cache",
+                                          "cross_kv")]
+
+
+SIGNATURES["eavqa_t5_decoder_step_workspace_bytes"] = [i32, i32, i32, i32, i32, i32]
+SIGNATURES["eavqa_t5_decoder_step"] = [i32, i32, C.POINTER(T5DecLayer), ptr, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, i32, ptr, ptr, ptr, i64,
+                                       ptr, i64, i32, ptr, i64, ptr]
 SIGNATURES["eavqa_lm_block_workspace_bytes"] = [i32, i32, i32, i32]
 SIGNATURES["eavqa_lm_block_forward"] = [i32, i32, C.POINTER(LMLayer), i32, i32, i32, i32, f32, i32, i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr]
 
@@ -82,7 +91,7 @@ SIGNATURES["eavqa_attention_bwd_ex"] = SIGNATURES["eavqa_attention_bwd"] + [i32]
 SIGNATURES["eavqa_gemm_splitk_ex"] = SIGNATURES["eavqa_gemm_splitk"] + [i32]
 SIGNATURES["eavqa_lm_block_forward_ex"] = SIGNATURES["eavqa_lm_block_forward"] + [i32]
 
-_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_lm_block_workspace_bytes": C.c_int64}
+_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_lm_block_workspace_bytes": C.c_int64, "eavqa_t5_decoder_step_workspace_bytes": C.c_int64}
 
 _lib = None
 

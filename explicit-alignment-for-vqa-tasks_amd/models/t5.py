@@ -19,7 +19,7 @@ from typing import Dict, List, Optional
 
 import torch
 
-from .. import ops
+from .. import _lib, ops
 
 Tensor = torch.Tensor
 
@@ -124,11 +124,43 @@ class _Block:
                  "w_qkv_t", "w_o_t", "w_q_ca_t", "w_kv_ca_t", "w_o_ca_t", "w_i_t", "w_o_ff_t")
 
 
+class _StepDriver:
+    """``eavqa_t5_decoder_step``: the calls of :meth:`FrozenT5.decode_step` issued from C++ (one ctypes call per step instead of ~340)."""
+
+    def __init__(self, lm: "FrozenT5", cache, kv, B: int, t_max: int):
+        c = lm.cfg
+        self.lm, self.B, self.t_max = lm, B, t_max
+        self.table = (_lib.T5DecLayer * len(lm.dec))()
+        p = lambda t: t.data_ptr()
+        for i, (b, (kc, vc), ckv) in enumerate(zip(lm.dec, cache, kv)):
+            e = self.table[i]
+            e.ln_sa, e.w_qkv, e.w_o = p(b.ln_sa), p(b.w_qkv), p(b.w_o)
+            e.ln_ca, e.w_q_ca, e.w_o_ca = p(b.ln_ca), p(b.w_q_ca), p(b.w_o_ca)
+            e.ln_ff, e.w_i, e.w_o_ff = p(b.ln_ff), p(b.w_i), p(b.w_o_ff)
+            e.k_cache, e.v_cache, e.cross_kv = p(kc), p(vc), p(ckv)
+        self.keep = (cache, kv)
+        dt = ops.dtype_id(lm.dtype)
+        nbytes = int(_lib.load().eavqa_t5_decoder_step_workspace_bytes(dt, B, c.d_model, c.inner, c.d_ff, int(c.gated)))
+        self.ws = torch.empty(nbytes, device=lm.device, dtype=torch.uint8)
+        self.out = torch.empty((B, c.d_model), device=lm.device, dtype=lm.dtype)
+
+    def step(self, y_last: Tensor, enc_mask: Tensor, t: int, S: int) -> Tensor:
+        lm, c = self.lm, self.lm.cfg
+        rel, zero = lm.rel_table(True, t)
+        _lib.call("eavqa_t5_decoder_step", ops.dtype_id(lm.dtype), len(lm.dec), self.table, lm.dec_final.data_ptr(), c.d_model, c.inner, c.n_head,
+                  c.d_ff, int(c.gated), _lib.ACT[c.act], float(c.eps), self.B, t, self.t_max, S, y_last.data_ptr(), self.out.data_ptr(),
+                  enc_mask.data_ptr() if enc_mask is not None else None, enc_mask.stride(0) if enc_mask is not None else 0, rel.data_ptr(), rel.stride(0),
+                  int(zero), self.ws.data_ptr(), self.ws.numel(),
+                  ops._stream())
+        return self.out
+
+
 class FrozenT5:
     """Weights of a frozen T5 encoder-decoder packed for the HIP kernels + forward / dgrad / greedy-generation drivers."""
 
     def __init__(self, cfg: T5Config, state_dict: Dict[str, Tensor], dtype: torch.dtype = torch.bfloat16, device="cuda"):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.native_step = True          # cached greedy steps through eavqa_t5_decoder_step (False: the same calls from Python, decode_step)
         T = lambda t: t.to(device=self.device, dtype=dtype).contiguous()
         F = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         sd = state_dict
@@ -409,9 +441,12 @@ class FrozenT5:
             t_max = max_length
             cache = [(torch.empty((B * t_max, c.inner), device=self.device, dtype=self.dtype),
                       torch.empty((B * t_max, c.inner), device=self.device, dtype=self.dtype)) for _ in self.dec]
+            driver = _StepDriver(self, cache, kv, B, t_max) if self.native_step else None
         t = P
         while t < max_length:
-            if cached:
+            if cached and driver is not None:
+                last = driver.step(self.embed(seq[:, t - 1].contiguous()), enc_mask, t, S)
+            elif cached:
                 last = self.decode_step(self.embed(seq[:, t - 1].contiguous()), cache, enc_mask, B, t, S, kv, t_max)
             else:
                 y = self.embed(seq[:, :t].contiguous())

@@ -288,6 +288,27 @@ int eavqa_lm_block_forward(int dtype, int n_layer, const eavqa_lm_layer_t* layer
                            int B, int Sq, int row0, int S_max, float* x, const int32_t* key_mask, int64_t ld_mask,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* One cached greedy step through all `n_layer` decoder layers of a frozen T5 (HF:models/t5/modeling_t5.py T5Block x n: self-attention with
+ * the relative-position bias, cross-attention over the encoder output, (gated) feed-forward; RMSNorm, no biases, unscaled scores), for the
+ * ONE new decoder position t - 1 of every sample: q / k / v of the new position, K / V appended to the per-layer cache [B, t_max, inner] at
+ * row t - 1, one query at the end of the t cached keys (bias rel_bias[h * rel_ld + (j - (t - 1)) + rel_zero]); cross-attention against
+ * cross_kv [B * S, 2 inner] = [K | V] of the encoder output (key mask row b at enc_mask + b * ld_mask).  x: float32 residual stream
+ * [B, E] = the input embedding of position t - 1, overwritten; out [B, E] `dtype` = final RMSNorm of the stack.  `layers` is a HOST
+ * array; weights in eavqa_gemm's b_kc layout ([out, in]; w_i = [wi_0; wi_1] when gated).  The call sequence of
+ * FrozenT5.decode_step (the reference runs HF generate: src/models/vct0.py:452-491), enqueue-only, no allocation. */
+typedef struct {
+    const float* ln_sa; const void* w_qkv; const void* w_o;            /* [3 inner, E], [E, inner] */
+    const float* ln_ca; const void* w_q_ca; const void* w_o_ca;        /* [inner, E], [E, inner] */
+    const float* ln_ff; const void* w_i; const void* w_o_ff;           /* [F or 2F, E], [E, F] */
+    void* k_cache; void* v_cache;                                       /* [B, t_max, inner] in `dtype` */
+    const void* cross_kv;                                               /* [B * S, 2 inner] in `dtype` */
+} eavqa_t5_dec_layer_t;
+int64_t eavqa_t5_decoder_step_workspace_bytes(int dtype, int B, int E, int inner, int F, int gated);
+int eavqa_t5_decoder_step(int dtype, int n_layer, const eavqa_t5_dec_layer_t* layers, const float* ln_final, int E, int inner, int H,
+                          int F, int gated, int act, float eps, int B, int t, int t_max, int S, float* x, void* out,
+                          const int32_t* enc_mask, int64_t ld_mask, const float* rel_bias, int64_t rel_ld, int rel_zero,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- decode-step primitives (M = batch <= 64 new tokens; replaces the eager per-step loop of
  * `_generate_from_embeddings`, src/models/clipcap.py:414-419, once a KV cache exists) --------------------------------
  * eavqa_gemm_splitk: bf16 A [M,K] x B [N,K]^T, K cut into `ks` slices over workgroups; fp32 partial sums

@@ -176,6 +176,24 @@ def test_vct0_generate_paths_match_reference_ids(tag):
     assert (torch.stack(list(o.scores))[:1] - want[:1]).abs().max().item() <= 8e-2 * max(1.0, want.abs().max().item())     # first step: same decoder prefix
 
 
+@pytest.mark.parametrize("tag", ["t0", "t5v10"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_vct0_native_decoder_step_is_the_python_call_sequence(tag, dtype):
+    """``eavqa_t5_decoder_step`` (one C call per greedy step) enqueues exactly the kernels of ``FrozenT5.decode_step``: scores bit-equal,
+    ids equal, for the gated (T0) and the ReLU (T5 v1.0) feed-forward."""
+    z, T, model, V = _model(tag, dtype)
+    model.eval()
+    kw = dict(prefix=T(z["fs_prefix"]), question_tokens=T(z["fs_tokens"]), question_mask=T(z["fs_mask"]), special_token_id=V - 1, max_length=9,
+              output_scores=True, return_dict_in_generate=True)
+    assert model.lm.native_step
+    a = model.generate(**kw)
+    model.lm.native_step = False
+    b = model.generate(**kw)
+    model.lm.native_step = True
+    assert torch.equal(a.sequences, b.sequences)
+    assert torch.equal(torch.stack(list(a.scores)), torch.stack(list(b.scores)))
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-2)])
 def test_vct0_cached_decoder_steps_equal_the_reforward_loop(dtype, tol):
     """``use_cache=True`` (one query against the self-attention K / V cache, B rows per step) against ``use_cache=False`` (the decoder re-run
