@@ -18,4 +18,4 @@ for i in range(iters): f(i)
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / iters
 mb = 2 * B * Sk * E * 2 / 1e6
-print(f"B={B} Sk={Sk}: {us:.1f} us, {mb:.1f} MB of K+V = {mb / us / 1e3:.2f} TB/s", flush=True)
+print(f"B={B} Sk={Sk}: {us:.1f} us, {mb:.1f} MB of K+V = {mb / us:.2f} TB/s", flush=True)
