@@ -121,6 +121,49 @@ def test_gemm_epilogue_activation_backward(ops, dtype, act, M):
     assert (out.cpu() - ref).abs().max().item() <= tol(dtype, 0.2)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(16448, 1024, 128, "res16"), (16448, 3072, 64, "bias"), (41120, 4096, 64, "quick"), (16576, 1024, 128, "aux")])
+def test_gemm_ragged_last_tile_row_goes_to_a_second_launch(ops, M, N, K, epi):
+    """256 x 256 kernel (forced): M % 256 <= 192 ragged rows are handed to a second, small-tile launch when the problem without them needs
+    one round of workgroups less (``big_split_rows``: 65 x 4 / 65 x 12 / 161 x 16 tiles here) - pointers of every row-indexed operand
+    (A, C, residual in place, pre-activation out) must be offset alike.  Exact integer data; the knob that keeps the single launch must
+    give the same bits."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-2, 3, (M, K), generator=g).to(torch.bfloat16).to(DEV)
+    b = torch.randint(-2, 3, (N, K), generator=g).to(torch.bfloat16).to(DEV)
+    bias = torch.randint(-3, 4, (N,), generator=g).float().to(DEV)
+    rows = torch.cat([torch.arange(0, 300), torch.arange(M - 700, M)])             # the first tiles, the boundary of the split, the remainder
+    pre = (a[rows].double() @ b.double().T + bias.double()).cpu()
+    res0 = torch.randint(-8, 9, (M, N), generator=g).to(torch.float16).to(DEV) if epi == "res16" else None
+    outs = []
+    for knob in ((2 << 14), (2 << 14) | (1 << 25)):                                  # forced 256 x 256: split allowed / single launch
+        ops.KernelSelect.gemm = knob
+        try:
+            if epi == "res16":
+                res = res0.clone()
+                want = pre + res[rows].double().cpu()
+                out = ops.gemm(a, b, bias=bias, residual=res, out=res)
+            elif epi == "aux":
+                u = torch.empty((M, N), device=DEV, dtype=torch.bfloat16)
+                out = ops.gemm(a, b, bias=bias, act="relu", aux_out=u)
+                want = pre.clamp(min=0)
+                assert torch.equal(u[rows].double().cpu(), pre)
+            elif epi == "quick":
+                out = ops.gemm(a, b, bias=bias, act="quick_gelu")
+                want = None
+            else:
+                out = ops.gemm(a, b, bias=bias)
+                want = pre
+        finally:
+            ops.KernelSelect.gemm = 0
+        if want is not None:
+            assert torch.equal(out[rows].double().cpu(), want), epi
+        else:
+            ref = pre * torch.sigmoid(1.702 * pre)
+            assert (out[rows].double().cpu() - ref).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item())
+        outs.append(out[rows].clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M,N,K", [(70, 264, 96), (300, 1024, 256), (2600, 768, 128), (33, 100, 64)])
 def test_gemm_low_precision_residual_stream(ops, gemm_path, M, N, K):
     """EAVQA_GEMM_RESIDUAL_LOWP: the residual (and here the output, aliasing it) in bf16 - the frozen CLIP tower's stream.  Exact
