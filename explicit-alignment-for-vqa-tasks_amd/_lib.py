@@ -78,6 +78,16 @@ class T5DecLayer(C.Structure):
                                           "cross_kv")]
 
 
+class DecodeGemm(C.Structure):
+    """``eavqa_decode_gemm_t``."""
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("A", ptr), ("lda", i64), ("a_kind", i32), ("gamma", ptr), ("beta", ptr), ("eps", f32),
+                ("stats_in", ptr), ("n_stats_in", i32), ("stats_in_cols", i32), ("B", ptr), ("ldb", i64), ("gated_rows", i32),
+                ("bias", ptr), ("act", i32), ("residual", ptr), ("ld_residual", i64), ("out_f32", i32), ("n_seg", i32),
+                ("out", ptr * 3), ("ld_out", i64 * 3), ("stats_out", ptr)]
+
+
+SIGNATURES["eavqa_gemm_decode_cols"] = [i32, i32, i32, i32, i32]
+SIGNATURES["eavqa_gemm_decode"] = [C.POINTER(DecodeGemm), ptr]
 SIGNATURES["eavqa_t5_decoder_step_workspace_bytes"] = [i32, i32, i32, i32, i32, i32]
 SIGNATURES["eavqa_t5_decoder_step"] = [i32, i32, C.POINTER(T5DecLayer), ptr, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, i32, ptr, ptr, ptr, i64,
                                        ptr, i64, i32, ptr, i64, ptr]
@@ -90,6 +100,7 @@ SIGNATURES["eavqa_attention_fwd_ex"] = SIGNATURES["eavqa_attention_fwd"] + [i32]
 SIGNATURES["eavqa_attention_bwd_ex"] = SIGNATURES["eavqa_attention_bwd"] + [i32]
 SIGNATURES["eavqa_gemm_splitk_ex"] = SIGNATURES["eavqa_gemm_splitk"] + [i32]
 SIGNATURES["eavqa_lm_block_forward_ex"] = SIGNATURES["eavqa_lm_block_forward"] + [i32]
+SIGNATURES["eavqa_gemm_decode_ex"] = SIGNATURES["eavqa_gemm_decode"] + [i32]
 
 _RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_lm_block_workspace_bytes": C.c_int64, "eavqa_t5_decoder_step_workspace_bytes": C.c_int64}
 

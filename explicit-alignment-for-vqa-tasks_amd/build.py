@@ -23,7 +23,7 @@ INCLUDE = os.path.join(ROOT, "include")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libeavqa_hip.so")
 
-HIP_SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "seq.hip", "loss.hip", "optim.hip", "decode.hip", "retrieval.hip"]
+HIP_SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "seq.hip", "loss.hip", "optim.hip", "decode.hip", "decode_direct.hip", "retrieval.hip"]
 CPP_SOURCES = ["api.cpp", "lm_block.cpp", "t5_block.cpp"]
 ARCH = "gfx950"
 

@@ -425,6 +425,48 @@ def layernorm_splitk(x_in: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_
     return y
 
 
+def gemm_decode_cols(M: int, N: int, K: int, a_kind: int = 0, gated: bool = False) -> int:
+    """Columns of C one workgroup of ``eavqa_gemm_decode`` owns (0: unsupported shape) - the width of one statistics partial."""
+    return int(_lib.load().eavqa_gemm_decode_cols(M, N, K, a_kind, int(gated)))
+
+
+def gemm_decode(a: Tensor, b: Tensor, outs, *, norm: Optional[str] = None, gamma: Optional[Tensor] = None, beta: Optional[Tensor] = None,
+                eps: float = 1e-5, stats_in: Optional[Tensor] = None, stats_in_cols: int = 0, gated: bool = False,
+                bias: Optional[Tensor] = None, act: str = "none", residual: Optional[Tensor] = None, want_stats: bool = False, sel: int = 0):
+    """The decode-step GEMM without partial sums (``eavqa_gemm_decode``): ``outs`` (1..3 2-D tensors, bf16 or fp32) receive equal
+    column segments of ``epilogue(norm(a) @ b^T)``.  ``norm``: None (``a`` bf16) | "layer" | "rms" (``a`` = the fp32 stream, ``stats_in``
+    [M, n, 2] from the producing call).  ``gated``: ``b`` = [wi_0; wi_1].  Returns the statistics partials [M, n, 2] of the output rows
+    when ``want_stats``.  ``sel`` (tests / tools): selector of ``eavqa_gemm_decode_ex``."""
+    M, K = a.shape
+    N = b.shape[0] // 2 if gated else b.shape[0]
+    a_kind = {None: 0, "layer": 1, "rms": 2}[norm]
+    g = _lib.DecodeGemm()
+    g.M, g.N, g.K = M, N, K
+    g.A, g.lda, g.a_kind = _p(a), _ld(a), a_kind
+    g.gamma, g.beta, g.eps = _p(gamma), _p(beta), float(eps)
+    if a_kind:
+        g.stats_in, g.n_stats_in, g.stats_in_cols = _p(stats_in), stats_in.shape[1], int(stats_in_cols)
+    g.B, g.ldb, g.gated_rows = _p(b), _ld(b), N if gated else 0
+    g.bias, g.act = _p(bias), _lib.ACT[act]
+    g.residual, g.ld_residual = _p(residual), residual.stride(0) if residual is not None else 0
+    g.out_f32, g.n_seg = int(outs[0].dtype == torch.float32), len(outs)
+    for i, o in enumerate(outs):
+        g.out[i], g.ld_out[i] = _p(o), o.stride(0)
+    stats = None
+    if want_stats:
+        nf = (sel & 0xF) * (8 if gated else 16) if (sel & 0xF) else gemm_decode_cols(M, N, K, a_kind, gated)
+        if nf <= 0:
+            raise _lib.EavqaError(f"eavqa_gemm_decode: unsupported shape M={M} N={N} K={K}")
+        stats = torch.empty((M, (N + nf - 1) // nf, 2), device=a.device, dtype=torch.float32)
+        g.stats_out = _p(stats)
+    import ctypes
+    if sel:
+        call("eavqa_gemm_decode_ex", ctypes.byref(g), _stream(), sel)
+    else:
+        call("eavqa_gemm_decode", ctypes.byref(g), _stream())
+    return stats
+
+
 def l2_normalize_rows_(x: Tensor) -> Tensor:
     """In place, fp32 [rows, cols] (faiss.normalize_L2)."""
     if x.dtype != torch.float32:

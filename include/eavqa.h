@@ -329,6 +329,35 @@ int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int
                            const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
                            float eps, void* y, int64_t ldy, void* stream);
 
+/* eavqa_gemm_decode: one weight-streaming GEMM of a decode step WITHOUT partial sums (csrc/decode_direct.hip):
+ *   C[m, n] = epilogue(sum_k norm(A)[m, k] * B[n, k]),  M <= 64 rows, B = a frozen bf16 [N, K] weight read once, K % 64 == 0.
+ * K is split over the eight waves of a workgroup that owns eavqa_gemm_decode_cols(M, N, K, a_kind, gated) columns of C, so the finished sums
+ * exist inside the kernel and the whole epilogue of eavqa_gemm runs there (bias, act, residual, fp32 or bf16 C) - plus:
+ *   a_kind 0: A is bf16 [M, K];  1 / 2: A is the fp32 residual stream and LayerNorm (HF:gpt2 :253-257, HF:opt :196-205) / T5 RMSNorm
+ *     (HF:t5 :50-72) is applied while loading it: gamma (beta: LayerNorm only) fp32 [K]; the row statistics come from `stats_in`
+ *     [M][n_stats_in][2] = (sum, sum of squared deviations from its own mean) of stats_in_cols consecutive columns each - what the
+ *     GEMM that produced the stream left in its `stats_out` (n_stats_in = ceil(its N / its eavqa_gemm_decode_cols)); combined in
+ *     index order, bitwise reproducible;
+ *   gated_rows = F != 0: B is T5's [wi_0; wi_1] ([2F, K]), N = F, C[m, n] = act(row n) * (row F + n) (HF:t5 :97-123);
+ *   n_seg (1..3): the N columns are cut into n_seg equal segments, segment j written to out[j] + m * ld_out[j] (n_seg = 3 with out[1] /
+ *     out[2] at the cache rows of the new position: "emit q, append k and v" in the QKV projection itself);
+ *   stats_out (NULL = skip): [M][ceil(N / cols)][2] statistics of the rows of C for the next normalising consumer.
+ * Replaces, for one new token per sample, the nn.Linear / Conv1D matmuls and the LayerNorm in front of them of HF:gpt2 :246-309,
+ * HF:opt :184-254, HF:t5 T5Block in the reference's greedy loops (src/models/clipcap.py:414-419, src/models/vct0.py:458-464). */
+typedef struct {
+    int M, N, K;
+    const void* A; int64_t lda; int a_kind;
+    const float* gamma; const float* beta; float eps;
+    const float* stats_in; int n_stats_in; int stats_in_cols;
+    const void* B; int64_t ldb; int gated_rows;
+    const float* bias; int act;
+    const float* residual; int64_t ld_residual;
+    int out_f32; int n_seg; void* out[3]; int64_t ld_out[3];
+    float* stats_out;
+} eavqa_decode_gemm_t;
+int eavqa_gemm_decode_cols(int M, int N, int K, int a_kind, int gated);     /* columns of C per workgroup; 0 = shape not supported */
+int eavqa_gemm_decode(const eavqa_decode_gemm_t* args, void* stream);
+
 /* ---- RICES retrieval (src/in_context_example_selection/get_question_knn.py:64-76: faiss.normalize_L2 +
  * IndexFlatIP.search with k = 2048).  The scores are eavqa_gemm in fp32 (queries [Nq, D] x database [Nd, D]^T).
  * eavqa_l2_normalize_rows: x[r, :] /= ||x[r, :]||_2 in place (rows of norm 0 untouched, as faiss).

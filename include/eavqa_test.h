@@ -63,6 +63,10 @@ int eavqa_lm_block_forward_ex(int dtype, int n_layer, const eavqa_lm_layer_t* la
                               int B, int Sq, int row0, int S_max, float* x, const int32_t* key_mask, int64_t ld_mask,
                               void* workspace, int64_t workspace_bytes, void* stream, int route);
 
+/* eavqa_gemm_decode with a selector: bits [3:0] force the 16-column fragments per workgroup (0 = by shape), bit 4 = plain instead of
+ * non-temporal weight loads, bits [11:8] = split the rows over that many workgroups per column group (0 = all rows in one). */
+int eavqa_gemm_decode_ex(const eavqa_decode_gemm_t* args, void* stream, int sel);
+
 #ifdef __cplusplus
 }
 #endif
