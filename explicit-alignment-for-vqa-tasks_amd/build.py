@@ -22,6 +22,7 @@ ROOT = os.path.dirname(PKG_DIR)
 INCLUDE = os.path.join(ROOT, "include")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(CSRC, "libeavqa_hip.so")
+EXPORTS = os.path.join(CSRC, "exports.map")
 
 HIP_SOURCES = ["gemm.hip", "norm.hip", "attention.hip", "seq.hip", "loss.hip", "optim.hip", "decode.hip", "decode_direct.hip", "retrieval.hip"]
 CPP_SOURCES = ["api.cpp", "lm_block.cpp", "t5_block.cpp"]
@@ -42,7 +43,9 @@ def _newer(dst: str, deps) -> bool:
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-FLAGS = ["-O3", "-std=c++17", "-fPIC"]
+# host side hidden: the .so exports exactly what include/eavqa.h and include/eavqa_test.h declare (their declarations carry default
+# visibility); device code keeps the toolchain default
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Xarch_host", "-fvisibility=hidden"]
 
 
 def _digest(rel_paths, extra: str) -> str:
@@ -100,8 +103,8 @@ def build(verbose: bool = False, force: bool = False) -> str:
     srcs = HIP_SOURCES + CPP_SOURCES
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
-    if not _newer(LIB, objs):
-        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+    if not _newer(LIB, objs + [EXPORTS]):
+        cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={EXPORTS}", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

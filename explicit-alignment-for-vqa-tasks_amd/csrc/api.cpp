@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 #include "eavqa.h"
+#include "eavqa_test.h"
 
 extern "C" int eavqa_abi_version(void) { return EAVQA_ABI_VERSION; }
 

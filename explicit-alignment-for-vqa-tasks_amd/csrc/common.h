@@ -5,6 +5,7 @@
 #include <float.h>
 #include <atomic>
 #include "eavqa.h"
+#include "eavqa_test.h"      // the *_ex entry points are defined next to the public ones: both declarations carry default visibility
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -35,10 +35,20 @@ struct DDArgs {
     int out_f32; int seg_cols; DDSeg seg[3];
     float2* stats_out;                        // [M][gridDim.x] or NULL
     int nt;                                   // weight loads with the non-temporal hint
+    unsigned a_bytes, b_bytes;                // extents of A and B for the buffer descriptors (< 2 GB)
 };
 
-template <bool NT> __device__ __forceinline__ bf16x8 ldw(const bf16_t* p) {
-    return NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)) : *reinterpret_cast<const bf16x8*>(p);
+// 16-byte buffer loads: a lane whose k-block lies past the end of K gets a byte offset beyond the descriptor's range - the range check
+// returns zeros and makes no memory request - so the K loop has NO branches around its loads (with `if (block < count) load` hipcc
+// merged the register ring into one set and waited vmcnt(0) after every block: one block in flight, 25 GB/s per CU).
+typedef __attribute__((vector_size(16))) unsigned int u32x4_t;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned OOB = 0x80000000u;              // buffers are < 2 GB (checked on the host)
+template <bool NT> __device__ __forceinline__ bf16x8 ldb16(rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, NT ? 2 : 0));
+}
+__device__ __forceinline__ float4 ldf4(rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
 __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
@@ -48,11 +58,11 @@ __device__ __forceinline__ bf16x8 pack8(const float (&v)[8]) {
     return r;
 }
 
-// Chan's parallel update of (count, mean, M2) with a second group
+// Chan's parallel update of (count, mean, M2) with a second group; branch-free (an empty group, nb = 0, changes nothing): a branch per
+// partial made hipcc wait vmcnt(0) - for the weight window - at every join
 __device__ __forceinline__ void chan(float& n, float& mean, float& m2, float nb, float meanb, float m2b) {
-    if (nb <= 0.f) return;
     const float nn = n + nb, d = meanb - mean;
-    const float f = nb * fast_rcp(nn);
+    const float f = nb > 0.f ? nb * fast_rcp(nn) : 0.f;
     mean += d * f;
     m2 += m2b + d * d * n * f;
     n = nn;
@@ -87,24 +97,38 @@ __global__ __launch_bounds__(512) void gemm_decode_direct_kernel(const DDArgs p)
     float* red = reinterpret_cast<float*>(smem);                  // [8][ROWS][PITCH]
     float* tile = red + 8 * ROWS * PITCH;                         // [ROWS][COLS + 1]
 
-    // ---- 1. (AF32) the loads everything else waits for go out first: statistics partials, gamma / beta
-    float2 st[AF32 ? 4 : 1];
-    const int srow = tid >> 3, spart = tid & 7;                   // 8 threads per row, partial i = spart + 8 q
+    // ---- 1. (AF32) what the A operand waits for goes out first: gamma / beta by LDS-DMA (no registers), then this workgroup's rows'
+    //         statistics partials - TPR threads per row, NQ partials each, ALL issued at once through a range-checked descriptor (no
+    //         branches: a loop of guarded loads made hipcc wait vmcnt(0) per pass, behind the weight loads below)
+    constexpr int TPR = 512 / ROWS, NQ = 256 / TPR;               // n_stats_in <= 256 (checked on the host)
+    const int m0 = blockIdx.y * ROWS;
+    const int srow = tid / TPR, spart = tid % TPR;
+    float2 st[AF32 ? NQ : 1];
     if (AF32) {
-        for (int i = tid * 4; i < K; i += 2048) {
-            *reinterpret_cast<float4*>(s_gamma + i) = *reinterpret_cast<const float4*>(p.gamma + i);
-            if (p.beta) *reinterpret_cast<float4*>(s_beta + i) = *reinterpret_cast<const float4*>(p.beta + i);
+        for (int base = wave * 64; base < K / 4; base += 512) {
+            const int c = base + lane;
+            if (c < K / 4) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.gamma + 4 * c),
+                                                 (__attribute__((address_space(3))) void*)(s_gamma + 4 * base), 16, 0, 0);
+                if (p.beta)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.beta + 4 * c),
+                                                     (__attribute__((address_space(3))) void*)(s_beta + 4 * base), 16, 0, 0);
+            }
         }
+        const rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(p.stats_in), 0, (unsigned)(M * p.n_stats_in * 8), 0x00020000);
+        const unsigned row_off = m0 + srow < M ? (unsigned)((m0 + srow) * p.n_stats_in * 8) : OOB;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = spart + 8 * q;
-            st[q] = make_float2(0.f, 0.f);
-            if (srow < M && i < p.n_stats_in) st[q] = p.stats_in[(int64_t)srow * p.n_stats_in + i];
+        for (int q = 0; q < NQ; ++q) {
+            const int i = spart + TPR * q;
+            st[q] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, i < p.n_stats_in ? row_off + 8u * i : OOB, 0, 0));
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- 2. weight rows of this lane; the first U blocks of B
-    const bf16_t* bp[NF];
+    const rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.B), 0, p.b_bytes, 0x00020000);
+    const rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, p.a_bytes, 0x00020000);
+    unsigned bo[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) {
         int n;
@@ -114,69 +138,58 @@ __global__ __launch_bounds__(512) void gemm_decode_direct_kernel(const DDArgs p)
         } else {
             n = min(n0 + 16 * j + x, p.N - 1);
         }
-        bp[j] = p.B + (int64_t)n * p.ldb + wave * 64 + 16 * g;
+        bo[j] = (unsigned)(((int64_t)n * p.ldb + wave * 64 + 16 * g) * 2);
     }
     bf16x8 wlo[U][NF], whi[U][NF];
-    auto load_w = [&](int u, int s) {
+    auto load_w = [&](int u, int s) {                 // block s of this wave = k-block wave + 8 s: 512 elements further along the row
+        const unsigned step = s < cnt ? (unsigned)s * 1024u : OOB;
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
-            wlo[u][j] = ldw<NT>(bp[j] + (int64_t)s * 512);
-            whi[u][j] = ldw<NT>(bp[j] + (int64_t)s * 512 + 8);
+            wlo[u][j] = ldb16<NT>(rb, bo[j] + step);
+            whi[u][j] = ldb16<NT>(rb, bo[j] + step + 16);
         }
     };
-    const int m0 = blockIdx.y * ROWS;
-    const char* ap[MF];
+    unsigned ao[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i)
-        ap[i] = reinterpret_cast<const char*>(p.A) + ((int64_t)min(m0 + 16 * i + x, M - 1) * p.lda + wave * 64 + 16 * g) * (AF32 ? 4 : 2);
+        ao[i] = (unsigned)(((int64_t)min(m0 + 16 * i + x, M - 1) * p.lda + wave * 64 + 16 * g) * (AF32 ? 4 : 2));
     bf16x8 alo[AF32 ? 1 : U][MF], ahi[AF32 ? 1 : U][MF];
     float4 araw[AF32 ? U : 1][MF][4];
     auto load_a = [&](int u, int s) {
+        const unsigned step = s < cnt ? (unsigned)s * (AF32 ? 2048u : 1024u) : OOB;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             if (AF32) {
-                const float4* src = reinterpret_cast<const float4*>(ap[i] + (int64_t)s * 2048);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) araw[u][i][c] = src[c];
+                for (int c = 0; c < 4; ++c) araw[u][i][c] = ldf4(ra, ao[i] + step + 16 * c);
             } else {
-                const bf16x8* src = reinterpret_cast<const bf16x8*>(ap[i] + (int64_t)s * 1024);
-                alo[u][i] = src[0];
-                ahi[u][i] = src[1];
+                alo[u][i] = ldb16<false>(ra, ao[i] + step);
+                ahi[u][i] = ldb16<false>(ra, ao[i] + step + 16);
             }
         }
     };
+    // (sched_barrier: the window must be ISSUED in slot order - the loop waits for slot 0 first, and the waits at the loop head cover both
+    // ways into it; hipcc had turned the prologue round, so every iteration began with vmcnt(0))
     if (!AF32) {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u < cnt) { load_a(u, u); load_w(u, u); }
+        for (int u = 0; u < U; ++u) { load_a(u, u); load_w(u, u); __builtin_amdgcn_sched_barrier(0); }
     } else {
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u < cnt) load_w(u, u);
+        for (int u = 0; u < U; ++u) { load_w(u, u); __builtin_amdgcn_sched_barrier(0); }
     }
 
-    // ---- 3. (AF32) row statistics: the partials of a row are combined in index order (Chan), 8 lanes per row, then across them
+    // ---- 3. (AF32) row statistics: a thread folds its partials in index order (Chan), then the TPR lanes of a row pairwise
     float rmean[MF], rrstd[MF];
     if (AF32) {
         float n = 0.f, mean = 0.f, m2 = 0.f;
-        for (int q0 = 0; q0 < p.n_stats_in; q0 += 32) {
-            if (q0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int i = q0 + spart + 8 * q;
-                    st[q] = make_float2(0.f, 0.f);
-                    if (srow < M && i < p.n_stats_in) st[q] = p.stats_in[(int64_t)srow * p.n_stats_in + i];
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = q0 + spart + 8 * q;
-                const float nb = i < p.n_stats_in ? (float)min(p.stats_in_cols, K - i * p.stats_in_cols) : 0.f;
-                chan(n, mean, m2, nb, nb > 0.f ? st[q].x / nb : 0.f, st[q].y);
-            }
+        for (int q = 0; q < NQ; ++q) {
+            const int i = spart + TPR * q;
+            const float nb = i < p.n_stats_in ? (float)min(p.stats_in_cols, K - i * p.stats_in_cols) : 0.f;
+            chan(n, mean, m2, nb, st[q].x * fast_rcp(fmaxf(nb, 1.f)), st[q].y);     // (no branch: see chan)
         }
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) {
+        for (int o = 1; o < TPR; o <<= 1) {
             const float nb = __shfl_xor(n, o, 64), mb = __shfl_xor(mean, o, 64), qb = __shfl_xor(m2, o, 64);
             // both partners must end with the same bits: the lower lane of the pair is always the left operand
             const bool lo = (spart & o) == 0;
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(512) void gemm_decode_direct_kernel(const DDArgs p)
             chan(n1, me1, q1, lo ? nb : n, lo ? mb : mean, lo ? qb : m2);
             n = n1; mean = me1; m2 = q1;
         }
-        if (spart == 0 && srow < 64) {
+        if (spart == 0) {
             const float inv = 1.f / (float)K;
             if (p.a_kind == 2) {                                  // RMSNorm: mean(x^2) = (M2 + n mean^2) / n
                 s_mean[srow] = 0.f;
@@ -194,16 +207,17 @@ __global__ __launch_bounds__(512) void gemm_decode_direct_kernel(const DDArgs p)
                 s_rstd[srow] = rsqrtf(m2 * inv + p.eps);
             }
         }
+        // the LDS-DMA of gamma / beta is older than the statistics loads just consumed; the wait below leaves only the U weight blocks
+        // issued after them in flight
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((2 * U * NF) & 0xF) | (((2 * U * NF) >> 4) << 14));
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
-            const int r = min(m0 + 16 * i + x, M - 1);
-            rmean[i] = s_mean[r];
-            rrstd[i] = s_rstd[r];
+            rmean[i] = s_mean[16 * i + x];                        // rows past M hold the statistics of nothing: their products are never stored
+            rrstd[i] = s_rstd[16 * i + x];
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            if (u < cnt) load_a(u, u);
+        for (int u = 0; u < U; ++u) { load_a(u, u); __builtin_amdgcn_sched_barrier(0); }
     }
 
     f32x4 acc[MF][NF];
@@ -212,50 +226,59 @@ __global__ __launch_bounds__(512) void gemm_decode_direct_kernel(const DDArgs p)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // ---- 4. K loop: slot u is refilled with block s + U as soon as its registers have been copied out
+    // ---- 4. K loop, branch-free inside: slot u is refilled with block s + U right BEHIND the MFMAs that read it (the load overwrites the
+    //         registers the MFMAs were issued from: no copies, so no loop-carried register moves that would wait for every load in
+    //         flight); blocks past the end load zeros (no memory request) and multiply zeros
     for (int s0 = 0; s0 < cnt; s0 += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int s = s0 + u;
-            if (s < cnt) {
-                bf16x8 bl[NF], bh[NF], al[MF], ah[MF];
+            if (AF32) {
+                const int kb = min((wave + 8 * s) * 64, K - 64) + 16 * g;
+                float4 gm[4], bt[4];
 #pragma unroll
-                for (int j = 0; j < NF; ++j) { bl[j] = wlo[u][j]; bh[j] = whi[u][j]; }
-                if (AF32) {
-                    const int kb = (wave + 8 * s) * 64 + 16 * g;
-                    float4 gm[4], bt[4];
+                for (int c = 0; c < 4; ++c) {
+                    gm[c] = *reinterpret_cast<const float4*>(s_gamma + kb + 4 * c);
+                    bt[c] = p.beta ? *reinterpret_cast<const float4*>(s_beta + kb + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                bf16x8 al[MF], ah[MF];
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    float v[16];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        gm[c] = *reinterpret_cast<const float4*>(s_gamma + kb + 4 * c);
-                        bt[c] = p.beta ? *reinterpret_cast<const float4*>(s_beta + kb + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 r = araw[u][i][c];
+                        v[4 * c + 0] = (r.x - rmean[i]) * rrstd[i] * gm[c].x + bt[c].x;
+                        v[4 * c + 1] = (r.y - rmean[i]) * rrstd[i] * gm[c].y + bt[c].y;
+                        v[4 * c + 2] = (r.z - rmean[i]) * rrstd[i] * gm[c].z + bt[c].z;
+                        v[4 * c + 3] = (r.w - rmean[i]) * rrstd[i] * gm[c].w + bt[c].w;
                     }
-#pragma unroll
-                    for (int i = 0; i < MF; ++i) {
-                        float v[16];
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            const float4 r = araw[u][i][c];
-                            v[4 * c + 0] = (r.x - rmean[i]) * rrstd[i] * gm[c].x + bt[c].x;
-                            v[4 * c + 1] = (r.y - rmean[i]) * rrstd[i] * gm[c].y + bt[c].y;
-                            v[4 * c + 2] = (r.z - rmean[i]) * rrstd[i] * gm[c].z + bt[c].z;
-                            v[4 * c + 3] = (r.w - rmean[i]) * rrstd[i] * gm[c].w + bt[c].w;
-                        }
-                        al[i] = pack8(reinterpret_cast<const float (&)[8]>(v[0]));
-                        ah[i] = pack8(reinterpret_cast<const float (&)[8]>(v[8]));
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < MF; ++i) { al[i] = alo[u][i]; ah[i] = ahi[u][i]; }
+                    al[i] = pack8(reinterpret_cast<const float (&)[8]>(v[0]));
+                    ah[i] = pack8(reinterpret_cast<const float (&)[8]>(v[8]));
                 }
-                if (s + U < cnt) { load_a(u, s + U); load_w(u, s + U); }
+                load_a(u, s + U);
 #pragma unroll
                 for (int i = 0; i < MF; ++i)
 #pragma unroll
                     for (int j = 0; j < NF; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], wlo[u][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], whi[u][j], acc[i][j], 0, 0, 0);
                     }
+                load_w(u, s + U);
+            } else {
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo[u][i], wlo[u][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi[u][i], whi[u][j], acc[i][j], 0, 0, 0);
+                    }
+                load_a(u, s + U);
+                load_w(u, s + U);
             }
+            // nothing crosses a block boundary: left alone, the scheduler hoists every MFMA of the U blocks to the top of the loop body
+            // behind one vmcnt(0) - the whole window drained once per iteration
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -371,7 +394,7 @@ static int gemm_decode_impl(const eavqa_decode_gemm_t* a, void* stream, int sel)
     if (a->a_kind < 0 || a->a_kind > 2) return EAVQA_E_DTYPE;
     if (a->act < EAVQA_ACT_NONE || a->act > EAVQA_ACT_QUICK_GELU) return EAVQA_E_DTYPE;
     const bool af32 = a->a_kind != 0;
-    if (af32 && (!a->gamma || !a->stats_in || a->n_stats_in <= 0 || a->stats_in_cols <= 0 || K > 16384)) return EAVQA_E_ARG;
+    if (af32 && (!a->gamma || !a->stats_in || a->n_stats_in <= 0 || a->n_stats_in > 256 || a->stats_in_cols <= 0 || K > 16384)) return EAVQA_E_ARG;
     if (af32 && (int64_t)a->n_stats_in * a->stats_in_cols < K) return EAVQA_E_ARG;      // the partials must cover the row
     if (a->lda < K || a->ldb < K || a->lda % (af32 ? 4 : 8) || a->ldb % 8) return EAVQA_E_ALIGN;
     if (!eavqa_aligned16(a->A) || !eavqa_aligned16(a->B) || (af32 && (!eavqa_aligned16(a->gamma) || (a->beta && !eavqa_aligned16(a->beta)))))
@@ -416,6 +439,15 @@ static int gemm_decode_impl(const eavqa_decode_gemm_t* a, void* stream, int sel)
     for (int i = 0; i < 3; ++i) { p.seg[i].dst = a->out[i]; p.seg[i].ld = a->ld_out[i]; }
     p.stats_out = reinterpret_cast<float2*>(a->stats_out);
     p.nt = nt;
+    {
+        const int64_t b_rows = a->gated_rows ? (int64_t)a->gated_rows + N : N;
+        const int64_t bb = ((b_rows - 1) * a->ldb + K) * 2, ab = ((int64_t)(M - 1) * a->lda + K) * (af32 ? 4 : 2);
+        if (bb >= (int64_t)OOB || ab >= (int64_t)OOB) return EAVQA_E_SHAPE;
+        p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+        // timing-only ablations (RESULTS ARE WRONG): an empty descriptor drops every load through it while the instruction stream stays
+        if (sel & 0x20) p.a_bytes = 0;
+        if (sel & 0x40) p.b_bytes = 0;
+    }
     const int out_cols = a->gated_rows ? 8 * nf : 16 * nf;
     const dim3 grid((N + out_cols - 1) / out_cols, row_groups);
     hipLaunchKernelGGL(kernel, grid, dim3(512), lds, reinterpret_cast<hipStream_t>(stream), p);

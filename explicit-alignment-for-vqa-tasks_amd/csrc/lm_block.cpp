@@ -7,6 +7,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "eavqa.h"
+#include "eavqa_test.h"
 
 namespace {
 inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "eavqa.h"
+#include "eavqa_test.h"
 
 namespace {
 inline size_t align_up(size_t v) { return (v + 255) & ~size_t(255); }

@@ -212,6 +212,8 @@ class ClipCapExecutor:
 
     # ------------------------------------------------------------------ checkpoints (mapper only + LM identity)
     def state_dict(self):
+        """COLLECTIVE under the sharded optimiser: every rank must call it (the reference saves on rank 0 only through Lightning's
+        ModelCheckpoint, src/main.py:97-110 - with ``ShardedAdamW`` call ``state_dict()`` on all ranks and write the file on one)."""
         # under the sharded optimiser (bf16 operand mode) every rank updates only ITS shards of the fp32 master copy: gather the
         # whole master first, or the checkpoint would hold stale rows for the shards this rank does not own
         gather = getattr(self.optimizer, "gather_master", None)

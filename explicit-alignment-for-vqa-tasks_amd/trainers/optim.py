@@ -8,6 +8,7 @@ buffers, which also refreshes the bf16 shadow used by the next forward.
 from __future__ import annotations
 
 import torch
+from typing import Optional
 
 from .. import ops
 
@@ -135,8 +136,13 @@ class ShardedAdamW:
     ``adamw`` is the update kernel (``ops.adamw``; the CPU tests inject a torch restatement - the product path has no CPU fallback)."""
 
     def __init__(self, flat, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, *, group=None,
-                 n_buckets: int = 4, adamw=None, collectives_in_group_of_one: bool = False):
+                 n_buckets: int = 4, adamw=None, collectives_in_group_of_one: bool = False, synchronous: Optional[bool] = None):
+        """``synchronous`` (default: the environment variable ``EAVQA_DP_SYNC=1``): the blocking order of round 2 - reduce-scatter,
+        AdamW, all-gather bucket by bucket, every collective waited for before the next call - as a fallback should the
+        asynchronous issue order (never run on more than one GPU) misbehave on a real RCCL group; same arithmetic, same result."""
+        import os
         import torch.distributed as dist
+        self.synchronous = (os.environ.get("EAVQA_DP_SYNC", "0") == "1") if synchronous is None else bool(synchronous)
         self.flat, self.group = flat, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -186,8 +192,21 @@ class ShardedAdamW:
         # updated.  Nothing blocks the host (RCCL work.wait() is a stream wait); gloo (CPU tests) blocks in wait(), same order.
         w_small = None
         if self.small and multi:
-            w_small = dist.all_reduce(fl.grad[:self.small], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w_small = dist.all_reduce(fl.grad[:self.small], op=dist.ReduceOp.SUM, group=self.group, async_op=not self.synchronous)
         rs = []
+        if multi and self.synchronous:
+            for b in range(self.n_buckets):
+                lo, hi, mine = self._bucket(b)
+                gs = self.gshard[b * self.piece:(b + 1) * self.piece]
+                dist.reduce_scatter_tensor(gs, fl.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                self.adamw(fl.master[mine:mine + self.piece], gs, self.m[b * self.piece:(b + 1) * self.piece],
+                           self.v[b * self.piece:(b + 1) * self.piece], shadow=fl.shadow[mine:mine + self.piece] if lowp else None, **kw)
+                dist.all_gather_into_tensor(fl.shadow[lo:hi], fl.shadow[mine:mine + self.piece], group=self.group)
+            if self.small:
+                self.adamw(fl.master[:self.small], fl.grad[:self.small], self.m_small, self.v_small, shadow=fl.shadow[:self.small] if lowp else None, **kw)
+            self._master_stale = lowp
+            fl.mark_shadow_fresh()
+            return
         if multi:
             for b in range(self.n_buckets):
                 lo, hi, _ = self._bucket(b)
@@ -252,9 +271,13 @@ class ShardedAdamW:
         self.flat.grad_live = False
 
     def gather_master(self) -> torch.Tensor:
-        """The whole fp32 master copy on every rank (checkpoints): non-owned shards are stale between steps in bf16 mode."""
+        """The whole fp32 master copy on every rank (checkpoints): non-owned shards are stale between steps in bf16 mode.
+        COLLECTIVE: every rank of the group must call it (one all-gather per bucket) - a rank-0-only checkpoint would hang the
+        others' next collective.  An update still running on the side stream (``start()`` without ``finish()``) is waited for first:
+        the gathers are queued on the current stream and would otherwise read half-updated shards."""
         import torch.distributed as dist
         fl = self.flat
+        self.finish()
         if self.multi and fl.shadow is not fl.master:
             for b in range(self.n_buckets):
                 lo, hi, mine = self._bucket(b)

@@ -29,6 +29,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with hidden visibility: exactly the entry points declared here are exported */
+#pragma GCC visibility push(default)
 
 #define EAVQA_ABI_VERSION 1
 
@@ -410,6 +412,7 @@ int eavqa_attention_bwd_rel(int dtype, int B, int H, int Sq, int Sk, int hd, con
 /* float32 -> `dtype` elementwise copy with row strides (casts the residual stream / pooled rows). */
 int eavqa_cast_rows(int dtype, int rows, int64_t cols, const float* x, int64_t ldx, void* y, int64_t ldy, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

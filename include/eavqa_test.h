@@ -13,6 +13,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with hidden visibility: exactly the entry points declared here are exported */
+#pragma GCC visibility push(default)
 
 /* eavqa_gemm with a kernel selector.  Bit fields of `knobs`:
  *   [3:0]   start-up delay (x 8 x 64 cycles) of every other co-resident workgroup of the round-1 128 x 128 LDS-DMA kernel (experiment)
@@ -64,9 +66,11 @@ int eavqa_lm_block_forward_ex(int dtype, int n_layer, const eavqa_lm_layer_t* la
                               void* workspace, int64_t workspace_bytes, void* stream, int route);
 
 /* eavqa_gemm_decode with a selector: bits [3:0] force the 16-column fragments per workgroup (0 = by shape), bit 4 = plain instead of
- * non-temporal weight loads, bits [11:8] = split the rows over that many workgroups per column group (0 = all rows in one). */
+ * non-temporal weight loads, bits [11:8] = split the rows over that many workgroups per column group (0 = all rows in one);
+ * bits 5 / 6: timing-only ablations - the A / the B operand is not fetched (zeros arrive instead: RESULTS ARE WRONG). */
 int eavqa_gemm_decode_ex(const eavqa_decode_gemm_t* args, void* stream, int sel);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,15 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
     assert sorted(_lib.SIGNATURES) == declared_symbols()
 
 
+def test_the_dynamic_symbol_table_is_exactly_the_two_headers():
+    """Hidden visibility + csrc/exports.map: no C++ symbol, kernel handle or toolchain bookkeeping symbol leaves the library."""
+    import subprocess
+    from eavqa_amd import build
+    out = subprocess.run(["nm", "-D", "--defined-only", build.build()], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == declared_symbols()
+
+
 def test_library_exports_no_mutable_global_switches(lib):
     """`no global mutable state` (include/eavqa.h conventions): the round-1 eavqa_debug_* setters are gone."""
     for name in ("eavqa_debug_disable_fast_gemm", "eavqa_debug_gemm_stagger", "eavqa_debug_attention_valu"):

@@ -131,8 +131,26 @@ def _sharded_worker(rank, world, port, results):
             for b in range(opt.n_buckets):
                 lo, hi, mine = opt._bucket(b)
                 ok = ok and bool(torch.allclose(flat.master[mine:mine + opt.piece], ref_p[mine:mine + opt.piece], atol=1e-6))
+        # a checkpoint taken between start() and finish(): gather_master() waits for the running update itself
+        grads = [torch.randn(flat.numel, generator=torch.Generator().manual_seed(900 + r)) for r in range(world)]
+        flat.grad.copy_(grads[rank])
+        opt.start()
         full = opt.gather_master()
-        ok = ok and bool(torch.allclose(full, ref_p, atol=1e-6))
+        oracle.adamw_step(ref_p, sum(grads) / world, ref_m, ref_v, 4, 0.05)
+        ok = ok and bool(torch.allclose(full, ref_p, atol=1e-6)) and not opt._busy
+        # the blocking fallback (synchronous=True / EAVQA_DP_SYNC=1) is the same arithmetic: bit-equal parameters
+        f2 = FlatParams(shapes, "cpu", cdt)
+        f2.master.copy_(init)
+        if f2.shadow is not f2.master:
+            f2.shadow.copy_(init.to(cdt))
+        o2 = ShardedAdamW(f2, lr=0.05, group=None, n_buckets=2, adamw=_cpu_adamw, synchronous=True)
+        for step in range(1, 4):
+            grads = [torch.randn(flat.numel, generator=torch.Generator().manual_seed(100 * step + r)) for r in range(world)]
+            f2.grad.copy_(grads[rank])
+            o2.step()
+        f2.grad.copy_([torch.randn(flat.numel, generator=torch.Generator().manual_seed(900 + r)) for r in range(world)][rank])
+        o2.step()
+        ok = ok and bool(torch.equal(o2.gather_master(), full)) and bool(torch.equal(f2.shadow, flat.shadow))
         out[str(cdt)] = ok
     results[rank] = out
     dist.destroy_process_group()
