@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .lm import KNOWN_CONFIGS, FrozenCausalLM, LMConfig, load_local_hf, random_init_state_dict
+from .lm import KNOWN_CONFIGS, FrozenCausalLM, LMConfig, load_local_hf, random_init_state_dict, synthetic_weights_notice
 
 Tensor = torch.Tensor
 
@@ -429,8 +429,11 @@ def _resolve_lm(model_version: str, dtype, device, seed: int = 2021, weight_form
             cfgd, sd = load_local_hf(cand)
             return FrozenCausalLM(LMConfig.from_hf_dict(cfgd), sd, dtype, device, weight_format)
     if model_version in KNOWN_CONFIGS:
+        synthetic_weights_notice(model_version)
         cfg = LMConfig.from_hf_dict(KNOWN_CONFIGS[model_version])
-        return FrozenCausalLM(cfg, random_init_state_dict(cfg, seed, device), dtype, device, weight_format)
+        lm = FrozenCausalLM(cfg, random_init_state_dict(cfg, seed, device), dtype, device, weight_format)
+        lm.synthetic_weights = True                   # executors / bench stamp their outputs with it
+        return lm
     raise FileNotFoundError(f"{model_version!r}: not a local HF directory and not a known architecture name; "
                             "no network access is attempted")
 

@@ -124,6 +124,18 @@ def random_init_state_dict(cfg: LMConfig, seed: int = 2021, device="cpu") -> Dic
     return sd
 
 
+def synthetic_weights_notice(model_version: str) -> None:
+    """A known architecture NAME without a local HF directory gets seeded random-init weights (there is no network): say so once per
+    name, loudly - answers and losses from such a model mean nothing - and refuse outright under ``EAVQA_REQUIRE_PRETRAINED=1``."""
+    if os.environ.get("EAVQA_REQUIRE_PRETRAINED", "0") == "1":
+        raise FileNotFoundError(f"{model_version!r}: no local HF directory (EAVQA_MODEL_DIR) and EAVQA_REQUIRE_PRETRAINED=1 forbids "
+                                "the seeded random-init stand-in")
+    import warnings
+    warnings.warn(f"{model_version!r} is not a local HF directory: using SEEDED RANDOM-INIT weights of that architecture (synthetic runs "
+                  "only; set EAVQA_MODEL_DIR to a directory of HF checkpoints, or EAVQA_REQUIRE_PRETRAINED=1 to make this an error)",
+                  RuntimeWarning, stacklevel=3)
+
+
 def load_local_hf(path: str):
     """(config dict, state dict) from a local HF directory: safetensors, else a torch file loaded
     with ``weights_only=True``.  Nothing is fetched from the network."""

@@ -144,9 +144,11 @@ class _StepDriver:
         self.ws = torch.empty(nbytes, device=lm.device, dtype=torch.uint8)
         self.out = torch.empty((B, c.d_model), device=lm.device, dtype=lm.dtype)
 
-    def step(self, y_last: Tensor, enc_mask: Tensor, t: int, S: int) -> Tensor:
+    def step(self, y_last: Tensor, enc_mask: Tensor, t: int, S: int, rel=None) -> Tensor:
+        """``rel``: the (table, zero index) of :meth:`FrozenT5.rel_table` for ANY length >= t - one table per generation (t_max) serves
+        every step: the kernel reads table[(key - query) + zero], the same values whatever the table's span."""
         lm, c = self.lm, self.lm.cfg
-        rel, zero = lm.rel_table(True, t)
+        rel, zero = rel if rel is not None else lm.rel_table(True, t)
         _lib.call("eavqa_t5_decoder_step", ops.dtype_id(lm.dtype), len(lm.dec), self.table, lm.dec_final.data_ptr(), c.d_model, c.inner, c.n_head,
                   c.d_ff, int(c.gated), _lib.ACT[c.act], float(c.eps), self.B, t, self.t_max, S, y_last.data_ptr(), self.out.data_ptr(),
                   enc_mask.data_ptr() if enc_mask is not None else None, enc_mask.stride(0) if enc_mask is not None else 0, rel.data_ptr(), rel.stride(0),
@@ -296,14 +298,14 @@ class FrozenT5:
         out, rf = ops.rmsnorm_fwd(x, self.dec_final, c.eps, T, save_stats=True)
         return out, (dict(layers=tape, x_last=x, rf=rf, enc_mask=enc_mask, B=B, Td=Td, S=S) if save else None)
 
-    def decode_step(self, y_last: Tensor, cache: List, enc_mask: Tensor, B: int, t: int, S: int, kv: List[Tensor], t_max: int) -> Tensor:
+    def decode_step(self, y_last: Tensor, cache: List, enc_mask: Tensor, B: int, t: int, S: int, kv: List[Tensor], t_max: int, rel=None) -> Tensor:
         """One cached decoder step: ``y_last`` float32 [B, E] is the input embedding of decoder position t - 1; the self-attention K / V of
         positions 0 .. t - 2 are in ``cache`` (per layer two [B * t_max, inner] row views), position t - 1 is appended here.  Same
         arithmetic as the last row of :meth:`decode` over t positions (one query at the END of t keys: causal offset and relative-position
         bias as there), on B rows instead of B * t - which keeps every GEMM on the M <= 64 weight-streaming kernels.  Returns [B, E]."""
         c, T = self.cfg, self.dtype
         I, H, dkv = c.inner, c.n_head, c.d_kv
-        rel, zero = self.rel_table(True, t)
+        rel, zero = rel if rel is not None else self.rel_table(True, t)     # (one table of span t_max per generation: see _StepDriver.step)
         x = y_last
         for li, b in enumerate(self.dec):
             a = ops.rmsnorm_fwd(x, b.ln_sa, c.eps, T)
@@ -442,12 +444,15 @@ class FrozenT5:
             cache = [(torch.empty((B * t_max, c.inner), device=self.device, dtype=self.dtype),
                       torch.empty((B * t_max, c.inner), device=self.device, dtype=self.dtype)) for _ in self.dec]
             driver = _StepDriver(self, cache, kv, B, t_max) if self.native_step else None
+            # ONE decoder bias table per generation (span t_max): a table per step length meant max_length - 1 host-built tables and a
+            # blocking pageable host -> device copy per step of the first generation
+            rel_gen = self.rel_table(True, t_max)
         t = P
         while t < max_length:
             if cached and driver is not None:
-                last = driver.step(self.embed(seq[:, t - 1].contiguous()), enc_mask, t, S)
+                last = driver.step(self.embed(seq[:, t - 1].contiguous()), enc_mask, t, S, rel_gen)
             elif cached:
-                last = self.decode_step(self.embed(seq[:, t - 1].contiguous()), cache, enc_mask, B, t, S, kv, t_max)
+                last = self.decode_step(self.embed(seq[:, t - 1].contiguous()), cache, enc_mask, B, t, S, kv, t_max, rel_gen)
             else:
                 y = self.embed(seq[:, :t].contiguous())
                 hid, _ = self.decode(y, enc_out, enc_mask, B, t, S, kv=kv)

@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from .. import ops
 from .clipcap import MLP, TransformerMapper
-from .lm import load_local_hf
+from .lm import load_local_hf, synthetic_weights_notice
 from .t5 import KNOWN_T5, FrozenT5, T5Config, random_init_t5_state_dict
 
 Tensor = torch.Tensor
@@ -30,8 +30,11 @@ def _resolve_t5(model_version: str, dtype, device, seed: int = 2021) -> FrozenT5
             cfgd, sd = load_local_hf(cand)
             return FrozenT5(T5Config.from_hf_dict(cfgd), sd, dtype, device)
     if model_version in KNOWN_T5:
+        synthetic_weights_notice(model_version)
         cfg = T5Config.from_hf_dict(KNOWN_T5[model_version])
-        return FrozenT5(cfg, random_init_t5_state_dict(cfg, seed, device), dtype, device)
+        lm = FrozenT5(cfg, random_init_t5_state_dict(cfg, seed, device), dtype, device)
+        lm.synthetic_weights = True
+        return lm
     raise FileNotFoundError(f"{model_version!r}: not a local HF directory and not a known architecture name; no network access is attempted")
 
 

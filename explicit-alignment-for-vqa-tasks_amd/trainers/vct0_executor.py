@@ -96,12 +96,14 @@ class FewShotVQAExecutor(VCT0Executor):
         if add.get("ensemble_one_shots", False):
             ids = ids.view(-1, add.num_shots, ids.shape[-1])
             mask = mask.view(-1, add.num_shots, mask.shape[-1])
-            outputs = self.generate_from_ensembles(ids, mask, emb, add.num_shots, max_length, num_shots=1, one_shots=True, sentinel=sentinel)
+            outputs = self.generate_from_ensembles(ids, mask, emb, add.num_shots, max_length, num_shots=1, one_shots=True, sentinel=sentinel,
+                                                   no_prefix=no_prefix, one_at_a_time=one_at_a_time)
         elif add.get("num_permutations_of_in_context_examples", 0) > 0:
             n = add.num_permutations_of_in_context_examples
             ids = ids.view(-1, n, ids.shape[-1])
             mask = mask.view(-1, n, mask.shape[-1])
-            outputs = self.generate_from_ensembles(ids, mask, emb, n, max_length, sentinel=sentinel)
+            outputs = self.generate_from_ensembles(ids, mask, emb, n, max_length, sentinel=sentinel, no_prefix=no_prefix,
+                                                   one_at_a_time=one_at_a_time)
         else:
             outputs = self.model.generate(question_tokens=ids, question_mask=mask, prefix=emb, decoder_input_ids=dec_ids,
                                           decoder_attention_mask=dec_mask, no_prefix=no_prefix,
@@ -116,16 +118,18 @@ class FewShotVQAExecutor(VCT0Executor):
                 "answers": sample_batched.get("answers")}
 
     def generate_from_ensembles(self, ids, mask, emb, num_ensembles: int, max_length: int, num_shots: Optional[int] = None, one_shots: bool = False,
-                                sentinel: int = 32099):
+                                sentinel: int = 32099, no_prefix: bool = False, one_at_a_time: bool = False):
         """few_shot_vqa_executor.py:293-332: one greedy generation per ensemble member; a sequence's score is the sum over its emitted
         tokens not in [0, 1, 2] of log softmax(step scores)[token] (token k is scored by step k - 1: the start token has no score);
-        ``np.argmax`` keeps the first best member."""
+        ``np.argmax`` keeps the first best member.  ``no_prefix`` / ``pass_examples_through_encoder_one_at_a_time`` travel to
+        ``model.generate`` as the reference forwards them (:304-314)."""
         B = ids.shape[0]
         batch_scores = np.zeros((B, num_ensembles))
         members = []
         for i in range(num_ensembles):
             clip = emb[:, [i, -1]] if one_shots else emb[:, i]                              # :298-302
             out = self.model.generate(question_tokens=ids[:, i].contiguous(), question_mask=mask[:, i].contiguous(), prefix=clip, num_shots=num_shots,
+                                      no_prefix=no_prefix, pass_examples_through_encoder_one_at_a_time=one_at_a_time,
                                       max_length=max_length, output_scores=True, return_dict_in_generate=True, special_token_id=sentinel)
             logp = torch.log(torch.stack(list(out.scores)).softmax(dim=-1))                 # [steps, B, V] (host tensors)
             for j, seq in enumerate(out.sequences.tolist()):
