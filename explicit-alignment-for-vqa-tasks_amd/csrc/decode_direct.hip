@@ -12,8 +12,9 @@
 //   * LayerNorm / RMSNorm of the A operand is applied WHILE LOADING it (a_kind 1 / 2: A is the fp32 residual stream): the statistics
 //     of a row come from the producing GEMM of that stream, which leaves one (sum, M2) pair per row and workgroup (`stats_out`,
 //     combined here in a fixed order with Chan's update - bitwise reproducible, no atomics);
-//   * a whole 128-byte line per weight row and load instruction pair (a lane owns 16 consecutive k of a 64-deep block; both MFMA
-//     operands use the same k permutation, so the contraction is unchanged).
+//   * a whole 128-byte line per weight row and load instruction pair (the two halves of a 64-deep k-block: each instruction fetches a
+//     contiguous 64-byte piece of 16 rows - four lanes side by side; a lane owning 32 consecutive bytes instead makes every
+//     instruction gather four separate 16-byte pieces per row and measured 35 GB/s per CU).
 // What it costs: every workgroup reads ALL of A (M x K), from L2.  At M = 32 that is as many bytes as its own weights when it owns 32
 // columns, twice as many with 16: fine for K = E (A = 160 KB), the reason FFN-down (K = 4 E) is the shape to measure against split-K.
 #include "common.h"
@@ -36,6 +37,7 @@ struct DDArgs {
     float2* stats_out;                        // [M][gridDim.x] or NULL
     int nt;                                   // weight loads with the non-temporal hint
     unsigned a_bytes, b_bytes;                // extents of A and B for the buffer descriptors (< 2 GB)
+    int rotate;                               // workgroup b starts its walk over K at its b-th block (every workgroup reads the same A)
 };
 
 // 16-byte buffer loads: a lane whose k-block lies past the end of K gets a byte offset beyond the descriptor's range - the range check
@@ -86,6 +88,8 @@ __global__ __launch_bounds__(512) void gemm_decode_direct_kernel(const DDArgs p)
     const int K = p.K, M = p.M;
     const int nblk = K >> 6;
     const int cnt = (nblk - wave + 7) >> 3;                       // this wave's k-blocks: wave, wave + 8, ...
+    const int rot = (p.rotate && cnt > 0) ? (int)(blockIdx.x % (unsigned)cnt) : 0;
+    auto blk = [&](int s) { const int t = s + rot; return t >= cnt ? t - cnt : t; };      // s-th block of this wave's walk
     const int out_cols = p.gate_rows ? COLS / 2 : COLS;
     const int n0 = blockIdx.x * out_cols;
 
@@ -138,33 +142,33 @@ __global__ __launch_bounds__(512) void gemm_decode_direct_kernel(const DDArgs p)
         } else {
             n = min(n0 + 16 * j + x, p.N - 1);
         }
-        bo[j] = (unsigned)(((int64_t)n * p.ldb + wave * 64 + 16 * g) * 2);
+        bo[j] = (unsigned)(((int64_t)n * p.ldb + wave * 64 + 8 * g) * 2);
     }
     bf16x8 wlo[U][NF], whi[U][NF];
     auto load_w = [&](int u, int s) {                 // block s of this wave = k-block wave + 8 s: 512 elements further along the row
-        const unsigned step = s < cnt ? (unsigned)s * 1024u : OOB;
+        const unsigned step = s < cnt ? (unsigned)blk(s) * 1024u : OOB;
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             wlo[u][j] = ldb16<NT>(rb, bo[j] + step);
-            whi[u][j] = ldb16<NT>(rb, bo[j] + step + 16);
+            whi[u][j] = ldb16<NT>(rb, bo[j] + step + 64);
         }
     };
     unsigned ao[MF];
 #pragma unroll
     for (int i = 0; i < MF; ++i)
-        ao[i] = (unsigned)(((int64_t)min(m0 + 16 * i + x, M - 1) * p.lda + wave * 64 + 16 * g) * (AF32 ? 4 : 2));
+        ao[i] = (unsigned)(((int64_t)min(m0 + 16 * i + x, M - 1) * p.lda + wave * 64 + 8 * g) * (AF32 ? 4 : 2));
     bf16x8 alo[AF32 ? 1 : U][MF], ahi[AF32 ? 1 : U][MF];
     float4 araw[AF32 ? U : 1][MF][4];
     auto load_a = [&](int u, int s) {
-        const unsigned step = s < cnt ? (unsigned)s * (AF32 ? 2048u : 1024u) : OOB;
+        const unsigned step = s < cnt ? (unsigned)blk(s) * (AF32 ? 2048u : 1024u) : OOB;
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
             if (AF32) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) araw[u][i][c] = ldf4(ra, ao[i] + step + 16 * c);
+                for (int c = 0; c < 4; ++c) araw[u][i][c] = ldf4(ra, ao[i] + step + 16 * (c & 1) + 128 * (c >> 1));
             } else {
                 alo[u][i] = ldb16<false>(ra, ao[i] + step);
-                ahi[u][i] = ldb16<false>(ra, ao[i] + step + 16);
+                ahi[u][i] = ldb16<false>(ra, ao[i] + step + 64);
             }
         }
     };
@@ -234,12 +238,12 @@ __global__ __launch_bounds__(512) void gemm_decode_direct_kernel(const DDArgs p)
         for (int u = 0; u < U; ++u) {
             const int s = s0 + u;
             if (AF32) {
-                const int kb = min((wave + 8 * s) * 64, K - 64) + 16 * g;
+                const int kb = min((wave + 8 * blk(min(s, max(cnt - 1, 0)))) * 64, K - 64) + 8 * g;
                 float4 gm[4], bt[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    gm[c] = *reinterpret_cast<const float4*>(s_gamma + kb + 4 * c);
-                    bt[c] = p.beta ? *reinterpret_cast<const float4*>(s_beta + kb + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    gm[c] = *reinterpret_cast<const float4*>(s_gamma + kb + 4 * (c & 1) + 32 * (c >> 1));
+                    bt[c] = p.beta ? *reinterpret_cast<const float4*>(s_beta + kb + 4 * (c & 1) + 32 * (c >> 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 bf16x8 al[MF], ah[MF];
 #pragma unroll
@@ -447,6 +451,7 @@ static int gemm_decode_impl(const eavqa_decode_gemm_t* a, void* stream, int sel)
         // timing-only ablations (RESULTS ARE WRONG): an empty descriptor drops every load through it while the instruction stream stays
         if (sel & 0x20) p.a_bytes = 0;
         if (sel & 0x40) p.b_bytes = 0;
+        p.rotate = (sel & 0x80) ? 1 : 0;
     }
     const int out_cols = a->gated_rows ? 8 * nf : 16 * nf;
     const dim3 grid((N + out_cols - 1) / out_cols, row_groups);

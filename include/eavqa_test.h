@@ -67,7 +67,7 @@ int eavqa_lm_block_forward_ex(int dtype, int n_layer, const eavqa_lm_layer_t* la
 
 /* eavqa_gemm_decode with a selector: bits [3:0] force the 16-column fragments per workgroup (0 = by shape), bit 4 = plain instead of
  * non-temporal weight loads, bits [11:8] = split the rows over that many workgroups per column group (0 = all rows in one);
- * bits 5 / 6: timing-only ablations - the A / the B operand is not fetched (zeros arrive instead: RESULTS ARE WRONG). */
+ * bit 7: every workgroup starts its walk over K at a different k-block; bits 5 / 6: timing-only ablations - the A / the B operand is not fetched (zeros arrive instead: RESULTS ARE WRONG). */
 int eavqa_gemm_decode_ex(const eavqa_decode_gemm_t* args, void* stream, int sel);
 
 #pragma GCC visibility pop

@@ -43,7 +43,7 @@ SHAPES = [(32, 2560, 2560), (32, 7680, 2560), (32, 2560, 10240), (1, 192, 64), (
 
 
 @pytest.mark.parametrize("M,N,K", SHAPES)
-@pytest.mark.parametrize("sel", [0, 0x10, 0x1, 0x2, 0x3, 0x4, 0x201])
+@pytest.mark.parametrize("sel", [0, 0x10, 0x1, 0x2, 0x3, 0x4, 0x201, 0x80, 0x82])
 def test_bf16_product_every_tile(ops, M, N, K, sel):
     """Plain product, every fragment count per workgroup (sel bits [3:0]), plain instead of non-temporal weight loads (bit 4), the rows
     split over two workgroups (0x201)."""

@@ -22,7 +22,7 @@ for what, N, K in (("qkv", 7680, 2560), ("out", 2560, 2560), ("fc1", 10240, 2560
     x = torch.randn(M, K, device=dev).to(bf)
     out = torch.empty((M, N), device=dev, dtype=bf)
     line = f"{what:4s} N={N:6d} K={K:6d} |"
-    for sel, tag in ((0, "full"), (0x20, "no A"), (0x40, "no B"), (0x60, "neither")):
+    for sel, tag in ((0, "full"), (0x80, "rotated"), (0x20, "no A"), (0x40, "no B"), (0x60, "neither")):
         us = timed(lambda i: ops.gemm_decode(x, ws[i % nb], [out], sel=sel))
         line += f" {tag} {us:6.1f} us |"
     print(line, flush=True)
