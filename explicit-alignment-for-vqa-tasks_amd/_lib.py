@@ -44,6 +44,9 @@ SIGNATURES = {
     "eavqa_gemm_splitk": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i32, ptr],
     "eavqa_splitk_finish": [i32, i32, i32, ptr, i32, ptr, i32, ptr, i64, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr],
     "eavqa_layernorm_splitk": [i32, i32, i32, ptr, i64, ptr, i32, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, ptr],
+    "eavqa_rmsnorm_splitk": [i32, i32, i32, ptr, i64, ptr, i32, ptr, i64, ptr, f32, ptr, i64, ptr],
+    "eavqa_splitk_finish_gated": [i32, i32, i32, ptr, i32, i32, ptr, i64, ptr],
+    "eavqa_attention_decode_splitk_rel": [i32, i32, i32, i32, i32, ptr, i32, i32, ptr, i64, ptr, i64, i64, ptr, i64, ptr, i64, f32, ptr, i64, i32, ptr],
     "eavqa_colsum": [i32, i32, i32, ptr, i64, ptr, i32, ptr],
     "eavqa_embed_assemble": [i32, i32, i32, ptr, ptr, ptr, i64, ptr, i64, ptr, i64, ptr, i64, ptr],
     "eavqa_embed_assemble_bwd": [i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr],
@@ -101,6 +104,7 @@ SIGNATURES["eavqa_attention_bwd_ex"] = SIGNATURES["eavqa_attention_bwd"] + [i32]
 SIGNATURES["eavqa_gemm_splitk_ex"] = SIGNATURES["eavqa_gemm_splitk"] + [i32]
 SIGNATURES["eavqa_lm_block_forward_ex"] = SIGNATURES["eavqa_lm_block_forward"] + [i32]
 SIGNATURES["eavqa_gemm_decode_ex"] = SIGNATURES["eavqa_gemm_decode"] + [i32]
+SIGNATURES["eavqa_t5_decoder_step_ex"] = SIGNATURES["eavqa_t5_decoder_step"] + [i32]
 
 _RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_lm_block_workspace_bytes": C.c_int64, "eavqa_t5_decoder_step_workspace_bytes": C.c_int64}
 

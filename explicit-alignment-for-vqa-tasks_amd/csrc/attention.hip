@@ -447,18 +447,21 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
                                                           int64_t ldo, int64_t bsq, int64_t bsk, const int32_t* __restrict__ key_mask,
                                                           int64_t ld_mask, float* __restrict__ lse, int H, int Sk, int hd, float scale,
                                                           const bf16_t* __restrict__ k_new, const bf16_t* __restrict__ v_new, int64_t ld_new,
-                                                          const float* __restrict__ qkv_part, int ks, const float* __restrict__ qkv_bias) {
+                                                          const float* __restrict__ qkv_part, int ks, const float* __restrict__ qkv_bias,
+                                                          int part_cols, int part_kv, const float* __restrict__ rel_bias, int64_t rel_ld, int rel_zero) {
     // k_new / v_new (eavqa_attention_decode): the K / V rows of the NEW position (key Sk - 1) still sit in the QKV projection's
     // output; the lanes that own that key take them from there and append them to the cache on the way (each 16-byte piece of a
     // cache row has exactly one owner lane), which saves the separate append pass of the decode step.
     // qkv_part (eavqa_attention_decode_splitk): q and the new K / V rows do not exist yet - the QKV projection left `ks` fp32 partial
     // sums [ks][B][3 E]; every lane adds up the 8 values it needs (slices in index order, then the bias, then rounded to bf16: exactly
-    // what eavqa_splitk_finish would have stored), which also saves the finish pass.
+    // what eavqa_splitk_finish would have stored), which also saves the finish pass.  part_cols = columns per row of the partial sums
+    // (3 H hd: q | k | v, part_kv != 0; H hd: a cross-attention's q alone, part_kv == 0 - nothing to append).
+    // rel_bias (T5, HF:t5 :217-279): score(j) += rel_bias[h * rel_ld + (j - (Sk - 1)) + rel_zero] - the one query sits at position Sk - 1.
     extern __shared__ float dec_sc[];                 // [4 heads][Sk] scores, then [4][DEC_WPH][128] partial outputs, then the V image
     constexpr int KPI = 64 / LPK;
     char* vimg = reinterpret_cast<char*>(dec_sc + 4 * Sk + 4 * DEC_WPH * 128);      // VLDS: [Sk][4 heads x hd] bf16
     const int cpk = hd >> 1;                          // 16-byte pieces per key in the image (4 heads x hd / 8)
-    const bool appended = qkv_part || k_new;
+    const bool appended = (qkv_part && part_kv) || k_new;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int hh = wave / DEC_WPH, part = wave % DEC_WPH;
     const int b = blockIdx.x, h = blockIdx.y * 4 + hh;
@@ -468,7 +471,7 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
     float* sc = dec_sc + hh * Sk;
     float* opart = dec_sc + 4 * Sk + (hh * DEC_WPH + part) * 128;
     constexpr int STEP = KPI * DEC_WPH * DEC_U;
-    const int E3 = 3 * H * hd;
+    const int E3 = part_cols;
     // bf16(sum_s P[s][b][col .. col+7] + bias[col ..]) - the value eavqa_splitk_finish stores
     auto from_part = [&](int col) -> bf16x8 {
         const float* p0 = qkv_part + (int64_t)b * E3 + col;
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
     // the new position: its one owner lane per 16-byte piece fetches (or sums up) the row and appends it to the cache
     bf16x8 knew = {}, vnew = {};
     bool own_new = false;
-    if (qkv_part || k_new) {
+    if (appended) {
         const int rem = (Sk - 1) % STEP, grp = rem / KPI;
         own_new = active && (rem % KPI) == sub && (grp % DEC_WPH) == part;
         if (own_new) {
@@ -582,7 +585,8 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
             for (int e = 0; e < 8; ++e) d += qf[e] * (float)kv[u][e];
 #pragma unroll
             for (int o = LPK >> 1; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
-            if (head_ok && dl == 0 && j < Sk) sc[j] = (mrow && mrow[j] == 0) ? -FLT_MAX : d * scale;
+            if (head_ok && dl == 0 && j < Sk)
+                sc[j] = (mrow && mrow[j] == 0) ? -FLT_MAX : d * scale + (rel_bias ? rel_bias[(int64_t)h * rel_ld + (j - (Sk - 1)) + rel_zero] : 0.f);
         }
     }
     // without the image, the first batch of V is fetched under the exchange and the softmax
@@ -667,7 +671,8 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
                               const int32_t* key_mask, int64_t ld_mask, const int32_t* cu_seqlens, int causal,
                               float scale, float* lse, void* stream, int path,
                               const void* k_new, const void* v_new, int64_t ld_new,
-                              const float* qkv_part = nullptr, int ks = 0, const float* qkv_bias = nullptr) {
+                              const float* qkv_part = nullptr, int ks = 0, const float* qkv_bias = nullptr, int part_cols = 0,
+                              const float* rel_bias = nullptr, int64_t rel_ld = 0, int rel_zero = 0) {
     const bool g_force_valu = (path & 1) != 0;      // include/eavqa_test.h: bf16 on the vector-ALU kernels
     if ((!q && !qkv_part) || !k || !v || !o) return EAVQA_E_ARG;
     int rc = check_common(dtype, B, H, Sq, Sk, hd);
@@ -713,7 +718,8 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
     hipLaunchKernelGGL((attn_decode_kernel<LPK, WPH, 10, VL>), grid, dim3(256 * WPH), lds, s, reinterpret_cast<const bf16_t*>(q), ldq,  \
                        reinterpret_cast<const bf16_t*>(k), ldk, reinterpret_cast<const bf16_t*>(v), ldv,                      \
                        reinterpret_cast<bf16_t*>(o), ldo, p.bsq, p.bsk, key_mask, p.ld_mask, lse, H, Sk, hd, scale,                  \
-                       reinterpret_cast<const bf16_t*>(k_new), reinterpret_cast<const bf16_t*>(v_new), ld_new, qkv_part, ks, qkv_bias)
+                       reinterpret_cast<const bf16_t*>(k_new), reinterpret_cast<const bf16_t*>(v_new), ld_new, qkv_part, ks, qkv_bias,        \
+                       part_cols ? part_cols : 3 * H * hd, part_cols == 0 || part_cols == 3 * H * hd, rel_bias, rel_ld, rel_zero)
         if (hd <= 64) { EAVQA_DEC(8); } else { EAVQA_DEC(16); }
 #undef EAVQA_DEC
 #undef EAVQA_DEC2
@@ -721,6 +727,7 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
         return EAVQA_OK;
     }
     if (k_new || v_new || qkv_part) return EAVQA_E_SHAPE;          // the append forms exist for the decode kernel only
+    if (rel_bias) return EAVQA_E_SHAPE;                            // (eavqa_attention_fwd_rel routes a bias to the tiled kernels itself)
     const bool wide = eavqa_attn_mfma::supported_wide(hd, Sq, Sk) && !(ldq % 8 || ldk % 8 || ldv % 8);
     if (dtype == EAVQA_BF16 && (eavqa_attn_mfma::supported(hd) || wide) && !g_force_valu) {
         eavqa_attn_mfma::Params m = {};
@@ -763,6 +770,18 @@ extern "C" int eavqa_attention_decode_splitk(int dtype, int B, int H, int Sk, in
     if ((H * hd) % 4 || !eavqa_aligned16(qkv_partials) || (qkv_bias && !eavqa_aligned16(qkv_bias))) return EAVQA_E_ALIGN;
     return attention_fwd_impl(dtype, B, H, 1, Sk, hd, nullptr, 8, k_cache, ldk, v_cache, ldv, o, ldo, 1, kv_batch_rows, key_mask, ld_mask,
                               nullptr, 1, scale, nullptr, stream, 0, nullptr, nullptr, 0, qkv_partials, ks, qkv_bias);
+}
+
+extern "C" int eavqa_attention_decode_splitk_rel(int dtype, int B, int H, int Sk, int hd, const float* partials, int ks, int part_cols,
+                                                 void* k, int64_t ldk, void* v, int64_t ldv, int64_t kv_batch_rows, void* o, int64_t ldo,
+                                                 const int32_t* key_mask, int64_t ld_mask, float scale, const float* rel_bias, int64_t rel_ld,
+                                                 int rel_zero, void* stream) {
+    if (!partials || ks <= 0) return EAVQA_E_ARG;
+    if (part_cols != H * hd && part_cols != 3 * H * hd) return EAVQA_E_SHAPE;
+    if ((H * hd) % 4 || !eavqa_aligned16(partials)) return EAVQA_E_ALIGN;
+    if (rel_bias && (rel_zero < Sk - 1 || rel_ld < rel_zero + 1)) return EAVQA_E_ARG;     // offsets -(Sk - 1) .. 0 are read
+    return attention_fwd_impl(dtype, B, H, 1, Sk, hd, nullptr, 8, k, ldk, v, ldv, o, ldo, 1, kv_batch_rows, key_mask, ld_mask,
+                              nullptr, 1, scale, nullptr, stream, 0, nullptr, nullptr, 0, partials, ks, nullptr, part_cols, rel_bias, rel_ld, rel_zero);
 }
 
 extern "C" int eavqa_attention_fwd(int dtype, int B, int H, int Sq, int Sk, int hd,

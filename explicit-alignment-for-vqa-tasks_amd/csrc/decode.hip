@@ -138,6 +138,27 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(int M, int N, const 
     else elem<T>::st4(reinterpret_cast<T*>(d.dst) + (int64_t)m * d.ld + nl, v);
 }
 
+// h[m, c] = act(sum_s P[s][m][c]) * sum_s P[s][m][F + c]: the finish of T5's [wi_0; wi_1] projection (HF:t5 :97-123); 4 columns per thread
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_gated_kernel(int M, int F, const float* __restrict__ P, int ks, int act, T* __restrict__ out,
+                                                                  int64_t ld) {
+    const int nq = F >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= M * nq) return;
+    const int m = idx / nq, n = (idx % nq) * 4;
+    const int64_t N2 = 2 * (int64_t)F;
+    float4 u = *reinterpret_cast<const float4*>(P + m * N2 + n), w = *reinterpret_cast<const float4*>(P + m * N2 + F + n);
+    for (int s = 1; s < ks; ++s) {
+        const float* ps = P + ((int64_t)s * M + m) * N2 + n;
+        const float4 a = *reinterpret_cast<const float4*>(ps), b = *reinterpret_cast<const float4*>(ps + F);
+        u.x += a.x; u.y += a.y; u.z += a.z; u.w += a.w;
+        w.x += b.x; w.y += b.y; w.z += b.z; w.w += b.w;
+    }
+    float4 v;
+    v.x = act_fwd(act, u.x) * w.x; v.y = act_fwd(act, u.y) * w.y; v.z = act_fwd(act, u.z) * w.z; v.w = act_fwd(act, u.w) * w.w;
+    elem<T>::st4(out + (int64_t)m * ld + n, v);
+}
+
 // one 512-thread workgroup per row (a decode step has at most 64 rows: parallelism must come from inside the row), the
 // partial-sum loads of eight slices in flight at once: x = x_in + bias + sum_s P[s]; y = LN(x) * gamma + beta
 constexpr int LNS_NT = 512;
@@ -153,7 +174,7 @@ template <typename T, int NV>
 __global__ __launch_bounds__(LNS_NT) void ln_splitk_kernel(int rows, int cols, const float* __restrict__ x_in, int64_t ldx,
                                                            const float* __restrict__ P, int ks, const float* __restrict__ bias,
                                                            float* __restrict__ x_out, int64_t ldxo, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, T* __restrict__ y, int64_t ldy) {
+                                                           const float* __restrict__ beta, float eps, T* __restrict__ y, int64_t ldy, int rms) {
     __shared__ float red[LNS_NT / 64];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = cols >> 2;
@@ -165,7 +186,7 @@ __global__ __launch_bounds__(LNS_NT) void ln_splitk_kernel(int rows, int cols, c
         if (c < nv) {
             v[i] = *reinterpret_cast<const float4*>(x_in + (int64_t)row * ldx + 4 * c);
             gm[i] = *reinterpret_cast<const float4*>(gamma + 4 * c);
-            bt[i] = *reinterpret_cast<const float4*>(beta + 4 * c);
+            bt[i] = rms ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(beta + 4 * c);
             if (bias) { const float4 b = *reinterpret_cast<const float4*>(bias + 4 * c); v[i].x += b.x; v[i].y += b.y; v[i].z += b.z; v[i].w += b.w; }
         }
     }
@@ -210,7 +231,8 @@ __global__ __launch_bounds__(LNS_NT) void ln_splitk_kernel(int rows, int cols, c
             s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
     }
-    const float mu = block_sum8(s, red) / (float)cols;
+    // rms (T5LayerNorm, HF:t5 :50-72): no mean subtraction, no bias - y = gamma * x * rsqrt(mean(x^2) + eps)
+    const float mu = rms ? 0.f : block_sum8(s, red) / (float)cols;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -329,9 +351,26 @@ extern "C" int eavqa_splitk_finish(int dtype, int M, int N, const float* partial
     return EAVQA_OK;
 }
 
-extern "C" int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,
-                                      const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
-                                      float eps, void* y, int64_t ldy, void* stream) {
+extern "C" int eavqa_splitk_finish_gated(int dtype, int M, int F, const float* partials, int ks, int act, void* out, int64_t ld, void* stream) {
+    if (dtype != EAVQA_BF16 && dtype != EAVQA_F32) return EAVQA_E_DTYPE;
+    if (!partials || !out || M <= 0 || F <= 0 || ks <= 0) return EAVQA_E_ARG;
+    if (F % 4 || ld % 4) return EAVQA_E_SHAPE;
+    if (act < EAVQA_ACT_NONE || act > EAVQA_ACT_QUICK_GELU) return EAVQA_E_DTYPE;
+    const int threads = M * (F / 4);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EAVQA_BF16)
+        hipLaunchKernelGGL(splitk_finish_gated_kernel<bf16_t>, dim3((threads + 255) / 256), dim3(256), 0, s, M, F, partials, ks, act,
+                           reinterpret_cast<bf16_t*>(out), ld);
+    else
+        hipLaunchKernelGGL(splitk_finish_gated_kernel<float>, dim3((threads + 255) / 256), dim3(256), 0, s, M, F, partials, ks, act,
+                           reinterpret_cast<float*>(out), ld);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
+static int norm_splitk_impl(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,
+                            const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
+                            float eps, void* y, int64_t ldy, void* stream, int rms) {
     if (dtype != EAVQA_BF16 && dtype != EAVQA_F32) return EAVQA_E_DTYPE;
     if (!x_in || !gamma || !beta || !y || rows <= 0 || cols <= 0 || ks < 0 || (ks > 0 && !partials)) return EAVQA_E_ARG;
     if (cols % 4 || cols > 64 * 4 * 16) return EAVQA_E_SHAPE;
@@ -341,7 +380,7 @@ extern "C" int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define EAVQA_LNS(T, NV)                                                                                                    \
     hipLaunchKernelGGL((ln_splitk_kernel<T, NV>), grid, block, 0, s, rows, cols, x_in, ldx, partials, ks, bias, x_out, ld_out, \
-                       gamma, beta, eps, reinterpret_cast<T*>(y), ldy)
+                       gamma, beta, eps, reinterpret_cast<T*>(y), ldy, rms)
     if (dtype == EAVQA_BF16) {
         if (nv <= 1) EAVQA_LNS(bf16_t, 1); else if (nv <= 2) EAVQA_LNS(bf16_t, 2); else EAVQA_LNS(bf16_t, 4);
     } else {
@@ -350,4 +389,16 @@ extern "C" int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float
 #undef EAVQA_LNS
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
+}
+
+extern "C" int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,
+                                      const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
+                                      float eps, void* y, int64_t ldy, void* stream) {
+    if (!beta) return EAVQA_E_ARG;
+    return norm_splitk_impl(dtype, rows, cols, x_in, ldx, partials, ks, bias, x_out, ld_out, gamma, beta, eps, y, ldy, stream, 0);
+}
+
+extern "C" int eavqa_rmsnorm_splitk(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,
+                                    float* x_out, int64_t ld_out, const float* gamma, float eps, void* y, int64_t ldy, void* stream) {
+    return norm_splitk_impl(dtype, rows, cols, x_in, ldx, partials, ks, nullptr, x_out, ld_out, gamma, gamma, eps, y, ldy, stream, 1);
 }

@@ -149,11 +149,14 @@ class _StepDriver:
         every step: the kernel reads table[(key - query) + zero], the same values whatever the table's span."""
         lm, c = self.lm, self.lm.cfg
         rel, zero = rel if rel is not None else lm.rel_table(True, t)
-        _lib.call("eavqa_t5_decoder_step", ops.dtype_id(lm.dtype), len(lm.dec), self.table, lm.dec_final.data_ptr(), c.d_model, c.inner, c.n_head,
-                  c.d_ff, int(c.gated), _lib.ACT[c.act], float(c.eps), self.B, t, self.t_max, S, y_last.data_ptr(), self.out.data_ptr(),
-                  enc_mask.data_ptr() if enc_mask is not None else None, enc_mask.stride(0) if enc_mask is not None else 0, rel.data_ptr(), rel.stride(0),
-                  int(zero), self.ws.data_ptr(), self.ws.numel(),
-                  ops._stream())
+        args = (ops.dtype_id(lm.dtype), len(lm.dec), self.table, lm.dec_final.data_ptr(), c.d_model, c.inner, c.n_head,
+                c.d_ff, int(c.gated), _lib.ACT[c.act], float(c.eps), self.B, t, self.t_max, S, y_last.data_ptr(), self.out.data_ptr(),
+                enc_mask.data_ptr() if enc_mask is not None else None, enc_mask.stride(0) if enc_mask is not None else 0, rel.data_ptr(), rel.stride(0),
+                int(zero), self.ws.data_ptr(), self.ws.numel(), ops._stream())
+        if lm.step_route:
+            _lib.call("eavqa_t5_decoder_step_ex", *args, int(lm.step_route))          # tests / A-B measurements (include/eavqa_test.h)
+        else:
+            _lib.call("eavqa_t5_decoder_step", *args)
         return self.out
 
 
@@ -163,6 +166,7 @@ class FrozenT5:
     def __init__(self, cfg: T5Config, state_dict: Dict[str, Tensor], dtype: torch.dtype = torch.bfloat16, device="cuda"):
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
         self.native_step = True          # cached greedy steps through eavqa_t5_decoder_step (False: the same calls from Python, decode_step)
+        self.step_route = 0              # eavqa_t5_decoder_step_ex route (0 = the library's choice; 1 = the round-3 call sequence)
         T = lambda t: t.to(device=self.device, dtype=dtype).contiguous()
         F = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
         sd = state_dict
@@ -306,6 +310,8 @@ class FrozenT5:
         c, T = self.cfg, self.dtype
         I, H, dkv = c.inner, c.n_head, c.d_kv
         rel, zero = rel if rel is not None else self.rel_table(True, t)     # (one table of span t_max per generation: see _StepDriver.step)
+        if self.splitk_step_plan(B, t, S) is not None and self.step_route != 1:
+            return self._decode_step_splitk(y_last, cache, enc_mask, B, t, S, kv, t_max, rel, zero)
         x = y_last
         for li, b in enumerate(self.dec):
             a = ops.rmsnorm_fwd(x, b.ln_sa, c.eps, T)
@@ -324,6 +330,51 @@ class FrozenT5:
             a3 = ops.rmsnorm_fwd(x2, b.ln_ff, c.eps, T)
             x, _ = self._ffn(b, a3, x2, False)
         return ops.rmsnorm_fwd(x, self.dec_final, c.eps, T)
+
+    def splitk_step_plan(self, B: int, t: int, S: int):
+        """The split counts of the six projections when a cached step can take the split-K route of ``eavqa_t5_decoder_step`` (bf16, B <= 64,
+        head dim a multiple of 8, every shape plannable) - the conditions of csrc/t5_block.cpp ``plan_t5`` -, else None."""
+        c = self.cfg
+        E, I, F = c.d_model, c.inner, c.d_ff
+        if self.dtype != torch.bfloat16 or B > 64 or E % 8 or I % 8 or F % 4 or c.d_kv % 8 or c.d_kv > 128 or t > 3584 or S > 3584:
+            return None
+        plan = _lib.load().eavqa_gemm_splitk_plan
+        ks = dict(qkv=plan(B, 3 * I, E), o=plan(B, E, I), qc=plan(B, I, E), wi=plan(B, (2 if c.gated else 1) * F, E), wo=plan(B, E, F))
+        return ks if all(v > 0 for v in ks.values()) else None
+
+    def _decode_step_splitk(self, y_last, cache, enc_mask, B, t, S, kv, t_max, rel, zero) -> Tensor:
+        """The split-K route of ``eavqa_t5_decoder_step`` call for call (csrc/t5_block.cpp): every projection leaves fp32 partial sums that its
+        consumer adds up - the RMSNorm pass, the decode attention (which also appends K / V), the gated finish."""
+        c, T = self.cfg, self.dtype
+        I, H, dkv = c.inner, c.n_head, c.d_kv
+        ks = self.splitk_step_plan(B, t, S)
+        x, x2, part = y_last, None, None
+        for li, b in enumerate(self.dec):
+            if li == 0:
+                a = ops.rmsnorm_splitk(x, b.ln_sa, c.eps, T)
+            else:
+                x = torch.empty_like(y_last)
+                a = ops.rmsnorm_splitk(x2, b.ln_sa, c.eps, T, part=part, x_out=x)
+            kc, vc = cache[li]
+            part = ops.gemm_splitk(a, b.w_qkv, ks=ks["qkv"])
+            ctx = ops.attention_decode_splitk_rel(part, kc, vc, B, H, t, dkv, kv_batch_rows=t_max, scale=1.0, rel_bias=rel, rel_zero=zero)
+            part = ops.gemm_splitk(ctx, b.w_o, ks=ks["o"])
+            x1 = torch.empty_like(y_last)
+            a = ops.rmsnorm_splitk(x, b.ln_ca, c.eps, T, part=part, x_out=x1)
+            part = ops.gemm_splitk(a, b.w_q_ca, ks=ks["qc"])
+            kvc = kv[li]
+            ctx = ops.attention_decode_splitk_rel(part, kvc[:, :I], kvc[:, I:], B, H, S, dkv, kv_batch_rows=S, key_mask=enc_mask, scale=1.0)
+            part = ops.gemm_splitk(ctx, b.w_o_ca, ks=ks["o"])
+            x2 = torch.empty_like(y_last)
+            a = ops.rmsnorm_splitk(x1, b.ln_ff, c.eps, T, part=part, x_out=x2)
+            part = ops.gemm_splitk(a, b.w_i, ks=ks["wi"])
+            if c.gated:
+                h = ops.splitk_finish_gated(part, c.act, T)
+            else:
+                h = torch.empty((B, c.d_ff), device=self.device, dtype=T)
+                ops.splitk_finish(part, [h], act=c.act)
+            part = ops.gemm_splitk(h, b.w_o_ff, ks=ks["wo"])
+        return ops.rmsnorm_splitk(x2, self.dec_final, c.eps, T, part=part)
 
     def logits(self, hidden: Tensor) -> Tensor:
         lg = torch.empty((hidden.shape[0], self.vpad), device=self.device, dtype=torch.float32)

@@ -425,6 +425,36 @@ def layernorm_splitk(x_in: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_
     return y
 
 
+def rmsnorm_splitk(x_in: Tensor, gamma: Tensor, eps: float, out_dtype, part: Optional[Tensor] = None, x_out: Optional[Tensor] = None,
+                   out: Optional[Tensor] = None) -> Tensor:
+    """x = x_in + sum(part) (-> ``x_out``); returns T5LayerNorm(x) in ``out_dtype`` (``eavqa_rmsnorm_splitk``)."""
+    rows, cols = x_in.shape
+    y = out if out is not None else torch.empty((rows, cols), device=x_in.device, dtype=out_dtype)
+    call("eavqa_rmsnorm_splitk", dtype_id(out_dtype), rows, cols, _p(x_in), _ld(x_in), _p(part), 0 if part is None else part.shape[0],
+         _p(x_out), _ld(x_out) if x_out is not None else 0, _p(gamma), float(eps), _p(y), _ld(y), _stream())
+    return y
+
+
+def splitk_finish_gated(part: Tensor, act: str, out_dtype) -> Tensor:
+    """h = act(sum(part)[:, :F]) * sum(part)[:, F:] for partial sums [ks, M, 2F] (``eavqa_splitk_finish_gated``)."""
+    ks, M, N2 = part.shape
+    h = torch.empty((M, N2 // 2), device=part.device, dtype=out_dtype)
+    call("eavqa_splitk_finish_gated", dtype_id(out_dtype), M, N2 // 2, _p(part), ks, _lib.ACT[act], _p(h), _ld(h), _stream())
+    return h
+
+
+def attention_decode_splitk_rel(part: Tensor, k: Tensor, v: Tensor, B: int, H: int, Sk: int, hd: int, *, kv_batch_rows: int,
+                                key_mask: Optional[Tensor] = None, scale: float = 1.0, rel_bias: Optional[Tensor] = None, rel_zero: int = 0) -> Tensor:
+    """One decode step of attention whose query (and, with 3 H hd columns, new K / V row) is summed from split-K partial sums
+    [ks, B, H hd | 3 H hd]; optional T5 relative-position bias table [H, ld] (``eavqa_attention_decode_splitk_rel``)."""
+    ks, _, cols = part.shape
+    o = torch.empty((B, H * hd), device=part.device, dtype=k.dtype)
+    call("eavqa_attention_decode_splitk_rel", dtype_id(k.dtype), B, H, Sk, hd, _p(part), ks, cols, _p(k), k.stride(0), _p(v), v.stride(0),
+         kv_batch_rows, _p(o), _ld(o), _p(key_mask), key_mask.stride(0) if key_mask is not None else 0, float(scale),
+         _p(rel_bias), rel_bias.stride(0) if rel_bias is not None else 0, int(rel_zero), _stream())
+    return o
+
+
 def gemm_decode_cols(M: int, N: int, K: int, a_kind: int = 0, gated: bool = False) -> int:
     """Columns of C one workgroup of ``eavqa_gemm_decode`` owns (0: unsupported shape) - the width of one statistics partial."""
     return int(_lib.load().eavqa_gemm_decode_cols(M, N, K, a_kind, int(gated)))

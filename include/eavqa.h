@@ -331,6 +331,23 @@ int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int
                            const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
                            float eps, void* y, int64_t ldy, void* stream);
 
+/* The same three consumers for a T5 decoder step (HF:models/t5/modeling_t5.py T5Block; the reference reaches it through HF generate,
+ * src/models/vct0.py:458-464):
+ * eavqa_rmsnorm_splitk: x = x_in + sum_s partials[s] (written to x_out when non-NULL); y = T5LayerNorm(x) (HF:t5 :50-72; no mean, no bias).
+ * eavqa_splitk_finish_gated: h[m, c] = act(sum_s P[s][m][c]) * sum_s P[s][m][F + c], P = partial sums [ks][M][2F] of x @ [wi_0; wi_1]^T
+ *   (T5DenseGatedActDense, HF:t5 :97-123).
+ * eavqa_attention_decode_splitk_rel: eavqa_attention_decode_splitk with T5's additive relative-position bias for the one query at
+ *   position Sk - 1 (score(j) += rel_bias[h * rel_ld + (j - (Sk - 1)) + rel_zero], NULL = none) and, with part_cols = H * hd, for partial
+ *   sums that hold q ALONE (cross-attention: nothing is appended, k / v = the encoder's projected rows); part_cols = 3 * H * hd: q | k | v
+ *   as eavqa_attention_decode_splitk.  No bias vector (T5's projections have none). */
+int eavqa_rmsnorm_splitk(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,
+                         float* x_out, int64_t ld_out, const float* gamma, float eps, void* y, int64_t ldy, void* stream);
+int eavqa_splitk_finish_gated(int dtype, int M, int F, const float* partials, int ks, int act, void* out, int64_t ld, void* stream);
+int eavqa_attention_decode_splitk_rel(int dtype, int B, int H, int Sk, int hd, const float* partials, int ks, int part_cols,
+                                      void* k, int64_t ldk, void* v, int64_t ldv, int64_t kv_batch_rows, void* o, int64_t ldo,
+                                      const int32_t* key_mask, int64_t ld_mask, float scale, const float* rel_bias, int64_t rel_ld,
+                                      int rel_zero, void* stream);
+
 /* eavqa_gemm_decode: one weight-streaming GEMM of a decode step WITHOUT partial sums (csrc/decode_direct.hip):
  *   C[m, n] = epilogue(sum_k norm(A)[m, k] * B[n, k]),  M <= 64 rows, B = a frozen bf16 [N, K] weight read once, K % 64 == 0.
  * K is split over the eight waves of a workgroup that owns eavqa_gemm_decode_cols(M, N, K, a_kind, gated) columns of C, so the finished sums

@@ -65,6 +65,13 @@ int eavqa_lm_block_forward_ex(int dtype, int n_layer, const eavqa_lm_layer_t* la
                               int B, int Sq, int row0, int S_max, float* x, const int32_t* key_mask, int64_t ld_mask,
                               void* workspace, int64_t workspace_bytes, void* stream, int route);
 
+/* eavqa_t5_decoder_step with the step structure as an argument: 0 = what the library does (split-K projections with fused consumers where
+ * every shape allows it), 1 = the round-3 call sequence (eavqa_gemm's M <= 64 kernels, separate RMSNorm / append / gate kernels). */
+int eavqa_t5_decoder_step_ex(int dtype, int n_layer, const eavqa_t5_dec_layer_t* layers, const float* ln_final, int E, int inner, int H,
+                             int F, int gated, int act, float eps, int B, int t, int t_max, int S, float* x, void* out,
+                             const int32_t* enc_mask, int64_t ld_mask, const float* rel_bias, int64_t rel_ld, int rel_zero,
+                             void* workspace, int64_t workspace_bytes, void* stream, int route);
+
 /* eavqa_gemm_decode with a selector: bits [3:0] force the 16-column fragments per workgroup (0 = by shape), bit 4 = plain instead of
  * non-temporal weight loads, bits [11:8] = split the rows over that many workgroups per column group (0 = all rows in one);
  * bit 7: every workgroup starts its walk over K at a different k-block; bits 5 / 6: timing-only ablations - the A / the B operand is not fetched (zeros arrive instead: RESULTS ARE WRONG). */

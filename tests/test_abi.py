@@ -33,7 +33,7 @@ def test_header_declares_the_expected_surface():
     assert not [n for n in public if "debug" in n or n.endswith("_ex")]
     assert set(declared_symbols(("eavqa_test.h",))) - set(public) == {"eavqa_gemm_ex", "eavqa_attention_fwd_ex", "eavqa_attention_bwd_ex",
                                                                                 "eavqa_gemm_splitk_ex", "eavqa_lm_block_forward_ex",
-                                                                                "eavqa_gemm_decode_ex"}
+                                                                                "eavqa_gemm_decode_ex", "eavqa_t5_decoder_step_ex"}
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):

@@ -107,6 +107,75 @@ def test_attention_with_relative_position_bias(ops, dtype, B, H, Sq, Sk, hd, cau
         assert (got.double().cpu().reshape(want.shape) - want).abs().max().item() <= tb * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols,ks", [(32, 2048, 8), (5, 64, 1), (64, 512, 10), (1, 4096, 0), (17, 1024, 3)])
+def test_rmsnorm_splitk_adds_the_partial_sums_first(ops, dtype, rows, cols, ks):
+    """eavqa_rmsnorm_splitk: x = x_in + sum_s P[s] (the new residual stream, float32); y = T5LayerNorm(x)."""
+    x_in, gamma = rnd(rows, cols, seed=1) + 0.2, 1.0 + rnd(cols, seed=2, scale=0.2)
+    part = rnd(max(ks, 1), rows, cols, seed=3, scale=0.5)
+    x_ref = x_in.double() + (part.double().sum(0) if ks else 0.0)
+    y_ref = x_ref * torch.rsqrt((x_ref ** 2).mean(-1, keepdim=True) + 1e-6) * gamma.double()
+    x_out = torch.full((rows, cols), float("nan"), device=DEV)
+    y = ops.rmsnorm_splitk(x_in.to(DEV), gamma.to(DEV), 1e-6, dtype, part=part.to(DEV) if ks else None, x_out=x_out)
+    assert (x_out.double().cpu() - x_ref).abs().max().item() <= 1e-5 * max(1.0, x_ref.abs().max().item())
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (y.double().cpu() - y_ref).abs().max().item() <= tol * max(1.0, y_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("act", ["gelu_new", "relu"])
+def test_splitk_finish_gated(ops, dtype, act):
+    M, F, ks = 9, 520, 4
+    part = rnd(ks, M, 2 * F, seed=1)
+    u = part.double().sum(0)
+    f = oracle.gelu_new if act == "gelu_new" else torch.relu
+    ref = f(u[:, :F].float()).double() * u[:, F:]
+    h = ops.splitk_finish_gated(part.to(DEV), act, dtype)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert (h.double().cpu() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,Sk,hd,cross,masked", [(2, 4, 1, 64, False, False), (3, 2, 9, 64, False, False), (32, 32, 10, 64, False, False),
+                                                    (2, 4, 150, 64, True, True), (32, 32, 170, 64, True, True), (2, 2, 14, 16, False, False),
+                                                    (2, 2, 37, 80, True, False), (2, 2, 20, 128, False, False)])
+def test_attention_decode_from_partial_sums_with_bias(ops, B, H, Sk, hd, cross, masked):
+    """eavqa_attention_decode_splitk_rel against eavqa_attention_fwd_rel on the q / K / V the partial sums add up to: a decoder self-attention
+    step (q | k | v partial sums, K / V appended at row Sk - 1, relative-position bias) and a cross-attention step (q alone, key mask)."""
+    from eavqa_amd.models.t5 import relative_bucket
+    bf = torch.bfloat16
+    I, ks, S_max = H * hd, 3, Sk + 2
+    cols = I if cross else 3 * I
+    part = rnd(ks, B, cols, seed=1, scale=0.6)
+    full = part.sum(0).to(bf)                                         # what a finish pass would store (fp32 sum in slice order, one rounding)
+    kc, vc = rnd(B * S_max, I, seed=2, dtype=bf).to(DEV), rnd(B * S_max, I, seed=3, dtype=bf).to(DEV)
+    km = None
+    if masked:
+        lens = torch.tensor([max(1, Sk - 3 * i - 1) for i in range(B)])
+        km = (torch.arange(Sk)[None] < lens[:, None]).int().to(DEV)
+    rel = zero = None
+    if not cross:
+        table = rnd(32, H, seed=5) * 0.7
+        off = torch.arange(-(Sk + 4), Sk + 5)                         # a table wider than this step needs (one table per generation)
+        rel, zero = table[relative_bucket(off, False, 32, 128)].T.contiguous().to(DEV), Sk + 4
+    kr, vr = kc.clone(), vc.clone()
+    if not cross:
+        kr.view(B, S_max, I)[:, Sk - 1] = full[:, I:2 * I].to(DEV)
+        vr.view(B, S_max, I)[:, Sk - 1] = full[:, 2 * I:].to(DEV)
+    q = full[:, :I].contiguous().to(DEV)
+    ref = ops.attention_fwd_rel(q, kr, vr, B, H, 1, Sk, hd, rel_bias=rel, rel_zero=zero or 0, key_mask=km, causal=not cross, scale=1.0,
+                                q_batch_rows=1, kv_batch_rows=S_max)
+    got = ops.attention_decode_splitk_rel(part.to(DEV), kc, vc, B, H, Sk, hd, kv_batch_rows=S_max, key_mask=km, scale=1.0, rel_bias=rel,
+                                          rel_zero=zero or 0)
+    torch.cuda.synchronize()
+    assert (got.float() - ref.float()).abs().max().item() <= 2e-2
+    if cross:
+        assert torch.equal(kc, kr) and torch.equal(vc, vr)                       # nothing appended
+    else:
+        assert torch.equal(kc.view(B, S_max, I)[:, Sk - 1], kr.view(B, S_max, I)[:, Sk - 1])       # the appended rows, bit for bit
+        assert torch.equal(vc.view(B, S_max, I)[:, Sk - 1], vr.view(B, S_max, I)[:, Sk - 1])
+        assert torch.equal(kc.view(B, S_max, I)[:, :Sk - 1], kr.view(B, S_max, I)[:, :Sk - 1])
+
+
 def _model(tag, dtype):
     from eavqa_amd.models.t5 import FrozenT5, T5Config
     from eavqa_amd.models.vct0 import VCT0Prefix
@@ -192,6 +261,23 @@ def test_vct0_native_decoder_step_is_the_python_call_sequence(tag, dtype):
     model.lm.native_step = True
     assert torch.equal(a.sequences, b.sequences)
     assert torch.equal(torch.stack(list(a.scores)), torch.stack(list(b.scores)))
+
+
+def test_vct0_splitk_step_route_is_taken_and_agrees_with_the_round3_sequence():
+    """bf16: the library's step takes the split-K route (plan present), and its per-step scores stay within bf16 rounding of the round-3 call
+    sequence's (different summation order inside the projections)."""
+    from eavqa_amd import _lib
+    z, T, model, V = _model("t0", torch.bfloat16)
+    model.eval()
+    assert model.lm.splitk_step_plan(2, 3, 20) is not None
+    kw = dict(prefix=T(z["fs_prefix"]), question_tokens=T(z["fs_tokens"]), question_mask=T(z["fs_mask"]), special_token_id=V - 1, max_length=9,
+              output_scores=True, return_dict_in_generate=True)
+    a = model.generate(**kw)
+    model.lm.step_route = 1
+    b = model.generate(**kw)
+    model.lm.step_route = 0
+    sa, sb = torch.stack(list(a.scores)), torch.stack(list(b.scores))
+    assert sa.shape[0] >= 1 and (sa[:1] - sb[:1]).abs().max().item() <= 6e-2 * max(1.0, sb.abs().max().item())
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-2)])

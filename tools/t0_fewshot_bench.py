@@ -66,3 +66,27 @@ for t in (1, 5, 9):
         return lm.logits(hid.view(B, t, -1)[:, -1].contiguous())
     h, d = hd(step)
     print(f"decoder pass over {t} token(s): host {h:.1f} ms, total {d:.1f} ms")
+
+# ---- the cached greedy step alone (eavqa_t5_decoder_step), the library's route against the round-3 call sequence
+from eavqa_amd.models.t5 import _StepDriver
+t_max = new
+cache = [(torch.empty((B * t_max, lm.cfg.inner), device=dev, dtype=dtype), torch.empty((B * t_max, lm.cfg.inner), device=dev, dtype=dtype)) for _ in lm.dec]
+driver = _StepDriver(lm, cache, kv, B, t_max)
+rel = lm.rel_table(True, t_max)
+y0 = lm.embed(torch.zeros((B, 1), dtype=torch.int64, device=dev)[:, 0].contiguous())
+for route in (0, 1):
+    lm.step_route = route
+    for t in range(1, t_max):
+        driver.step(y0.clone(), mask, t, S, rel)
+    torch.cuda.synchronize()
+    e0, e1 = ev(), None
+    for rep in range(3):
+        for t in range(1, t_max):
+            driver.step(y0.clone(), mask, t, S, rel)
+    e1 = ev(); torch.cuda.synchronize()
+    w = sum(p.numel() * 2 for blk in lm.dec for p in (blk.w_qkv, blk.w_o, blk.w_q_ca, blk.w_o_ca, blk.w_i, blk.w_o_ff))
+    kvb = len(lm.dec) * B * S * 2 * lm.cfg.inner * 2
+    ms = e0.elapsed_time(e1) / (3 * (t_max - 1))
+    print(f"cached decoder step, route {route} ({'split-K' if route == 0 else 'round-3 sequence'}): {ms:.3f} ms per step; weights {w / 1e9:.2f} GB + cross K/V "
+          f"{kvb / 1e9:.2f} GB per step = {(w + kvb) / ms / 1e9:.2f} TB/s = {(w + kvb) / ms / 1e9 / 8:.3f} of 8 TB/s")
+lm.step_route = 0
