@@ -441,7 +441,22 @@ int check_common(int dtype, int B, int H, int Sq, int Sk, int hd) {
 // whole V slice of the workgroup ([Sk keys][4 heads x hd], 100 KiB at Sk = 160, hd = 80) is fetched by LDS-DMA at the very start,
 // costs no registers, and P.V reads it from LDS: the kernel is ONE HBM round trip.  Taken when the image fits (<= 128 KiB) and
 // the grid is one workgroup per CU.
-template <int LPK, int DEC_WPH, int DEC_U, bool VLDS>
+// Phase timestamps of workgroup (0, 0), one row per wave: only in the profiling build (tools/attn_stamps.sh, -DEAVQA_ATTN_STAMPS); the
+// shipped library compiles EAVQA_STAMP to nothing.
+#ifdef EAVQA_ATTN_STAMPS
+__device__ unsigned long long eavqa_attn_stamps[16 * 16];
+#define EAVQA_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0) eavqa_attn_stamps[(threadIdx.x >> 6) * 16 + (i)] = wall_clock64(); } while (0)
+#else
+#define EAVQA_STAMP(i) do { } while (0)
+#endif
+
+// VMODE 2 (round 4): BOTH batches in registers and in flight from the first instruction on - K, then V - on workgroups of 4 heads x 1 or 2
+// waves (at most 8 waves per CU: 256 VGPRs each, room for 2 x DEC_U x 4 data registers).  tools/attn_stamps.py showed where the LDS-image
+// kernel's 20 us go: ISSUING the ~100 LDS-DMA instructions of a CU takes 4.3 us for its first wave and 9.6 us for its sixteenth (an LDS-DMA
+// holds the CU's issue for ~40 ns), the K loads queue behind them, and every wave then waits at the barrier for the last one's scores
+// (15.4 us).  Plain loads issue in ~1 us and the kernel is one HBM round trip.  DEC_WPH == 1 (a head's keys fit one wave's batch: T5's
+// decoder self-attention, <= 80 keys) also drops the cross-wave exchange of partial outputs and its barrier.
+template <int LPK, int DEC_WPH, int DEC_U, int VMODE>
 __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                           int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv, bf16_t* __restrict__ out,
                                                           int64_t ldo, int64_t bsq, int64_t bsk, const int32_t* __restrict__ key_mask,
@@ -458,6 +473,8 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
     // (3 H hd: q | k | v, part_kv != 0; H hd: a cross-attention's q alone, part_kv == 0 - nothing to append).
     // rel_bias (T5, HF:t5 :217-279): score(j) += rel_bias[h * rel_ld + (j - (Sk - 1)) + rel_zero] - the one query sits at position Sk - 1.
     extern __shared__ float dec_sc[];                 // [4 heads][Sk] scores, then [4][DEC_WPH][128] partial outputs, then the V image
+    EAVQA_STAMP(0);
+    constexpr bool VLDS = VMODE == 1, VREG = VMODE == 2;
     constexpr int KPI = 64 / LPK;
     char* vimg = reinterpret_cast<char*>(dec_sc + 4 * Sk + 4 * DEC_WPH * 128);      // VLDS: [Sk][4 heads x hd] bf16
     const int cpk = hd >> 1;                          // 16-byte pieces per key in the image (4 heads x hd / 8)
@@ -529,6 +546,16 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
         kv0[u] = (bf16x8){};
         if (active && j < Sk) kv0[u] = *reinterpret_cast<const bf16x8*>(kb + (int64_t)j * ldk);    // row Sk-1 may be stale: patched below
     }
+    bf16x8 vpre[VREG ? DEC_U : 1];                    // VMODE 2: the first batch of V right behind it (same patch for row Sk-1)
+    if (VREG) {
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u) {
+            const int j = key_of(0, u);
+            vpre[u] = (bf16x8){};
+            if (active && j < Sk) vpre[u] = *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
+        }
+    }
+    EAVQA_STAMP(1);
     // the new position: its one owner lane per 16-byte piece fetches (or sums up) the row and appends it to the cache
     bf16x8 knew = {}, vnew = {};
     bool own_new = false;
@@ -548,6 +575,7 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
             if (VLDS) *reinterpret_cast<bf16x8*>(vimg + ((Sk - 1) * cpk + hh * (hd >> 3) + dl) * 16) = vnew;
         }
     }
+    EAVQA_STAMP(2);
     float qf[8];
     {
         bf16x8 t = {};
@@ -564,19 +592,9 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
         return *reinterpret_cast<const bf16x8*>(vb + (int64_t)j * ldv);
     };
     const int32_t* mrow = key_mask ? key_mask + (int64_t)b * ld_mask : nullptr;
+    EAVQA_STAMP(3);
 
-    for (int j0 = 0; j0 < Sk; j0 += STEP) {
-        bf16x8 kv[DEC_U];
-#pragma unroll
-        for (int u = 0; u < DEC_U; ++u) {
-            const int j = key_of(j0, u);
-            if (j0 == 0) {
-                kv[u] = (own_new && j == Sk - 1) ? knew : kv0[u];
-            } else {
-                kv[u] = (bf16x8){};
-                if (active && j < Sk) kv[u] = load_k(j);
-            }
-        }
+    auto score = [&](const bf16x8 (&kv)[DEC_U], int j0) {
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
             const int j = key_of(j0, u);
@@ -588,20 +606,39 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
             if (head_ok && dl == 0 && j < Sk)
                 sc[j] = (mrow && mrow[j] == 0) ? -FLT_MAX : d * scale + (rel_bias ? rel_bias[(int64_t)h * rel_ld + (j - (Sk - 1)) + rel_zero] : 0.f);
         }
+    };
+    // first batch: the registers loaded at kernel start, the stale new row patched in place (no copy: with 2 x 20 loads held a second
+    // set of K registers spilled 137 VGPRs)
+#pragma unroll
+    for (int u = 0; u < DEC_U; ++u)
+        if (own_new && key_of(0, u) == Sk - 1) kv0[u] = knew;
+    score(kv0, 0);
+    for (int j0 = STEP; j0 < Sk; j0 += STEP) {
+        bf16x8 kv[DEC_U];
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u) {
+            const int j = key_of(j0, u);
+            kv[u] = (bf16x8){};
+            if (active && j < Sk) kv[u] = load_k(j);
+        }
+        score(kv, j0);
     }
+    EAVQA_STAMP(4);
     // without the image, the first batch of V is fetched under the exchange and the softmax
-    bf16x8 v0[VLDS ? 1 : DEC_U];
-    if (!VLDS) {
+    bf16x8 v0[VMODE == 0 ? DEC_U : 1];
+    if (VMODE == 0) {
 #pragma unroll
         for (int u = 0; u < DEC_U; ++u) {
             const int j = key_of(0, u);
             v0[u] = (bf16x8){};
             if (active && j < Sk) v0[u] = load_v(j);
         }
-    } else {
+    } else if (VLDS) {
         __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);      // vmcnt(0): this wave's share of the V image has landed
     }
+    EAVQA_STAMP(5);
     __syncthreads();
+    EAVQA_STAMP(6);
     float mx = -FLT_MAX;
     for (int j = lane; j < Sk; j += 64) mx = fmaxf(mx, sc[j]);
     mx = wave_max(mx);
@@ -609,6 +646,7 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
     for (int j = lane; j < Sk; j += 64) sum += __expf(sc[j] - mx);
     sum = wave_sum(sum);
 
+    EAVQA_STAMP(7);
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto accumulate = [&](const bf16x8 (&vv)[DEC_U], int j0) {
 #pragma unroll
@@ -619,7 +657,13 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
             for (int e = 0; e < 8; ++e) o[e] += pj * (float)vv[u][e];
         }
     };
-    if (!VLDS) accumulate(reinterpret_cast<const bf16x8 (&)[DEC_U]>(v0), 0);
+    if (VMODE == 0) accumulate(reinterpret_cast<const bf16x8 (&)[DEC_U]>(v0), 0);
+    if (VREG) {
+#pragma unroll
+        for (int u = 0; u < DEC_U; ++u)
+            if (own_new && key_of(0, u) == Sk - 1) vpre[u] = vnew;
+        accumulate(reinterpret_cast<const bf16x8 (&)[DEC_U]>(vpre), 0);
+    }
     for (int j0 = VLDS ? 0 : STEP; j0 < Sk; j0 += STEP) {
         bf16x8 vv[DEC_U];
 #pragma unroll
@@ -635,6 +679,19 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
     for (int e = 0; e < 8; ++e)
 #pragma unroll
         for (int off = LPK; off < 64; off <<= 1) o[e] += __shfl_xor(o[e], off, 64);
+    EAVQA_STAMP(8);
+    if (DEC_WPH == 1) {                               // the wave holds its head's whole output: no exchange
+        if (sub == 0 && active) {
+            const float inv = 1.f / sum;
+            bf16x8 r;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[e] = (bf16_t)(o[e] * inv);
+            *reinterpret_cast<bf16x8*>(out + (int64_t)b * bsq * ldo + h * hd + 8 * dl) = r;
+        }
+        if (lse && head_ok && lane == 0) lse[(int64_t)b * H + h] = mx + __logf(sum);
+        EAVQA_STAMP(9);
+        return;
+    }
     __syncthreads();                                  // every wave is done reading the scores: reuse nothing of theirs
     if (sub == 0 && active) {
 #pragma unroll
@@ -655,6 +712,7 @@ __global__ __launch_bounds__(256 * DEC_WPH) void attn_decode_kernel(const bf16_t
         *reinterpret_cast<bf16x8*>(out + (int64_t)b * bsq * ldo + h * hd + 8 * dl) = r;
     }
     if (lse && head_ok && part == 0 && lane == 0) lse[(int64_t)b * H + h] = mx + __logf(sum);
+    EAVQA_STAMP(9);
 }
 
 bool decode_supported(int dtype, int Sq, int Sk, int hd, const int32_t* cu, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo) {
@@ -694,6 +752,29 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
         eavqa_aligned16(v) && eavqa_aligned16(o)) {
         const dim3 grid(B, (H + 3) / 4);
         const int blocks = B * ((H + 3) / 4);
+        const int kpi = hd <= 64 ? 8 : 4;
+#define EAVQA_DEC2(LPK, WPH, U, VM)                                                                                          \
+    hipLaunchKernelGGL((attn_decode_kernel<LPK, WPH, U, VM>), grid, dim3(256 * WPH), lds, s, reinterpret_cast<const bf16_t*>(q), ldq,  \
+                       reinterpret_cast<const bf16_t*>(k), ldk, reinterpret_cast<const bf16_t*>(v), ldv,                      \
+                       reinterpret_cast<bf16_t*>(o), ldo, p.bsq, p.bsk, key_mask, p.ld_mask, lse, H, Sk, hd, scale,                  \
+                       reinterpret_cast<const bf16_t*>(k_new), reinterpret_cast<const bf16_t*>(v_new), ld_new, qkv_part, ks, qkv_bias,        \
+                       part_cols ? part_cols : 3 * H * hd, part_cols == 0 || part_cols == 3 * H * hd, rel_bias, rel_ld, rel_zero)
+        // one workgroup per CU and a head's keys within two batches of one or two waves: everything in registers, one HBM round trip
+        // (path bit 4, include/eavqa_test.h: keep the round-3 LDS-image kernel for A / B measurements and its parity tests)
+        // Taken where it measured faster (profiles/round4_decode_attention.md): one wave per head (<= 80 / 40 keys: 9.5 -> 6.6 us) and two
+        // waves x 10 loads (T0-3B cross-attention, 150 keys x 64: 16.9 -> 13.9 us).  Two waves x 20 loads (OPT-2.7B, 160 keys x 80) landed
+        // its 204 KB per CU no sooner than the LDS-image kernel (22.6 against 21.1 us): path bit 5 selects it for measurements only.
+        if (blocks <= 256 && Sk <= kpi * 2 * ((path & 32) ? 20 : 10) && !(path & 16)) {
+            const int wph = Sk <= kpi * 10 ? 1 : 2, u = Sk <= kpi * wph * 10 ? 10 : 20;
+            const size_t lds = ((size_t)4 * Sk + 4 * wph * 128) * sizeof(float);
+            if (hd <= 64) {
+                if (wph == 1) EAVQA_DEC2(8, 1, 10, 2); else if (u == 10) EAVQA_DEC2(8, 2, 10, 2); else EAVQA_DEC2(8, 2, 20, 2);
+            } else {
+                if (wph == 1) EAVQA_DEC2(16, 1, 10, 2); else if (u == 10) EAVQA_DEC2(16, 2, 10, 2); else EAVQA_DEC2(16, 2, 20, 2);
+            }
+            EAVQA_LAUNCH_CHECK();
+            return EAVQA_OK;
+        }
         const int wph = blocks <= 256 ? 4 : (blocks <= 512 ? 2 : 1);
         const size_t v_image = (size_t)Sk * 4 * hd * 2;
         // the V image rides in LDS only when the WHOLE request (scores + per-wave scratch + image) fits the 150 KiB the kernel opts into;
@@ -705,21 +786,15 @@ static int attention_fwd_impl(int dtype, int B, int H, int Sq, int Sk, int hd,
             static std::atomic<bool> configured[2];              // zero-initialised; concurrent first calls only repeat an idempotent call
             const int slot = hd <= 64 ? 0 : 1;
             if (!configured[slot].load(std::memory_order_acquire)) {
-                const void* fn = hd <= 64 ? reinterpret_cast<const void*>(attn_decode_kernel<8, 4, 10, true>)
-                                          : reinterpret_cast<const void*>(attn_decode_kernel<16, 4, 10, true>);
+                const void* fn = hd <= 64 ? reinterpret_cast<const void*>(attn_decode_kernel<8, 4, 10, 1>)
+                                          : reinterpret_cast<const void*>(attn_decode_kernel<16, 4, 10, 1>);
                 if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return EAVQA_E_LAUNCH;
                 configured[slot].store(true, std::memory_order_release);
             }
         }
 #define EAVQA_DEC(LPK)                                                                                                       \
-    if (vlds) EAVQA_DEC2(LPK, 4, true); else if (wph == 4) EAVQA_DEC2(LPK, 4, false); else if (wph == 2) EAVQA_DEC2(LPK, 2, false); \
-    else EAVQA_DEC2(LPK, 1, false)
-#define EAVQA_DEC2(LPK, WPH, VL)                                                                                             \
-    hipLaunchKernelGGL((attn_decode_kernel<LPK, WPH, 10, VL>), grid, dim3(256 * WPH), lds, s, reinterpret_cast<const bf16_t*>(q), ldq,  \
-                       reinterpret_cast<const bf16_t*>(k), ldk, reinterpret_cast<const bf16_t*>(v), ldv,                      \
-                       reinterpret_cast<bf16_t*>(o), ldo, p.bsq, p.bsk, key_mask, p.ld_mask, lse, H, Sk, hd, scale,                  \
-                       reinterpret_cast<const bf16_t*>(k_new), reinterpret_cast<const bf16_t*>(v_new), ld_new, qkv_part, ks, qkv_bias,        \
-                       part_cols ? part_cols : 3 * H * hd, part_cols == 0 || part_cols == 3 * H * hd, rel_bias, rel_ld, rel_zero)
+    if (vlds) EAVQA_DEC2(LPK, 4, 10, 1); else if (wph == 4) EAVQA_DEC2(LPK, 4, 10, 0); else if (wph == 2) EAVQA_DEC2(LPK, 2, 10, 0); \
+    else EAVQA_DEC2(LPK, 1, 10, 0)
         if (hd <= 64) { EAVQA_DEC(8); } else { EAVQA_DEC(16); }
 #undef EAVQA_DEC
 #undef EAVQA_DEC2
@@ -771,6 +846,12 @@ extern "C" int eavqa_attention_decode_splitk(int dtype, int B, int H, int Sk, in
     return attention_fwd_impl(dtype, B, H, 1, Sk, hd, nullptr, 8, k_cache, ldk, v_cache, ldv, o, ldo, 1, kv_batch_rows, key_mask, ld_mask,
                               nullptr, 1, scale, nullptr, stream, 0, nullptr, nullptr, 0, qkv_partials, ks, qkv_bias);
 }
+
+#ifdef EAVQA_ATTN_STAMPS
+extern "C" __attribute__((visibility("default"))) int eavqa_attn_stamps_read(unsigned long long* host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(eavqa_attn_stamps), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -5;
+}
+#endif
 
 extern "C" int eavqa_attention_decode_splitk_rel(int dtype, int B, int H, int Sk, int hd, const float* partials, int ks, int part_cols,
                                                  void* k, int64_t ldk, void* v, int64_t ldv, int64_t kv_batch_rows, void* o, int64_t ldo,

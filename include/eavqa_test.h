@@ -39,7 +39,9 @@ int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
  * ones), bit 1 (backward) takes the dQ + dK/dV kernel pair even when the problem is one tile, bit 2 (forward) keeps the
  * streamed-tile matrix-core kernel where the K / V-resident one (hd 64, no mask, Sq == Sk <= 592) would be chosen, bit 3 (forward)
  * takes the resident kernel also for Sk <= 64; bit 2 (backward) keeps the round-2 padded-pitch one-tile kernel where the swizzled
- * hd = 64 one (bwd_fused64_kernel) would be chosen. */
+ * hd = 64 one (bwd_fused64_kernel) would be chosen; bit 4 (forward, one query per sample): keep the round-3 decode kernel (V image in
+ * LDS, 16 waves) where the round-4 all-in-registers one (<= 8 waves, K and V in flight from the first instruction) would be chosen; bit 5:
+ * take the all-in-registers kernel also for key counts that need 2 x 20 loads per wave (measured slower than the LDS image). */
 int eavqa_attention_fwd_ex(int dtype, int B, int H, int Sq, int Sk, int hd,
                            const void* q, int64_t ldq, const void* k, int64_t ldk,
                            const void* v, int64_t ldv, void* o, int64_t ldo,

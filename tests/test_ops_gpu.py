@@ -569,9 +569,19 @@ def test_attention_decode_from_qkv_partial_sums(ops, B, H, hd, Sk, S_max, ks):
 
 @pytest.mark.parametrize("B,H,Sk,hd,masked", [(3, 5, 157, 80, True), (2, 8, 300, 128, False), (2, 4, 40, 64, True), (1, 3, 7, 32, False),
                                               (32, 32, 160, 80, True), (1, 4, 3584, 64, False), (1, 4, 3600, 64, False)])
-def test_attention_decode_step(ops, B, H, Sk, hd, masked):
+@pytest.mark.parametrize("path", [0, 16, 32])
+def test_attention_decode_step(ops, B, H, Sk, hd, masked, path):
     """Sq = 1 in bf16 takes the decode kernel (4 heads per workgroup, K/V streamed once): cache with a batch stride, ragged
-    masks, H not a multiple of 4."""
+    masks, H not a multiple of 4.  path 16 keeps the round-3 kernels (V image in LDS / V behind the scores) where round 4's
+    all-in-registers kernel would be chosen."""
+    ops.KernelSelect.attention = path
+    try:
+        _attention_decode_step(ops, B, H, Sk, hd, masked)
+    finally:
+        ops.KernelSelect.attention = 0
+
+
+def _attention_decode_step(ops, B, H, Sk, hd, masked):
     E, Smax = H * hd, Sk + 9
     ck, cv = rnd(B, Smax, E, dtype=torch.bfloat16, seed=1), rnd(B, Smax, E, dtype=torch.bfloat16, seed=2)
     q = rnd(B, E, dtype=torch.bfloat16, seed=3)
