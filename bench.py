@@ -18,7 +18,8 @@ Rank 0 prints ONE JSON line (contract in the task description) that also carries
                  bounded sample of the same workload (N = 1, rank 0 only), and
   extra        - (default cfg2 run, N = 1) a list of the other 1-GPU BASELINE configs, each in the same shape:
                  few-shot VQA2 generate (cfg4, questions/s, per-phase roofline), cfg3 bf16 and cfg5 fp8 training
-                 (5 warm-up + 10 timed steps each, own roofline).
+                 (5 warm-up + 10 timed steps each, own roofline), and the reference's own headline model, T0_3B:
+                 few-shot generate (t0_3b_fewshot) and Conceptual-Captions mapper training (t0_3b_cc_train).
 """
 from __future__ import annotations
 
@@ -244,6 +245,169 @@ def fewshot_qps(dtype, device, reps=3):
             "roofline": roof}
 
 
+T0 = dict(vit="ViT-L/14", lm="bigscience/T0_3B", prefix_length=10, fewshot_batch=32, shots=4, seg_len=20, new_tokens=10, train_batch=64, text_len=32,
+          desc="the reference's headline model (SURVEY F2): CLIP ViT-L/14 -> MLP mapper -> T0_3B (T5 v1.1 XL encoder-decoder), VCT0Prefix, prefix 10")
+
+
+def _t0_models(dtype, device, train):
+    from eavqa_amd.models.clip_vit import KNOWN_VITS, ClipVisionEncoder, random_init_vit_state_dict
+    from eavqa_amd.models.t5 import KNOWN_T5, FrozenT5, T5Config, random_init_t5_state_dict
+    from eavqa_amd.models.vct0 import VCT0Prefix
+    vcfg = KNOWN_VITS[T0["vit"]]
+    vit = ClipVisionEncoder(vcfg, random_init_vit_state_dict(vcfg, 2021, device), dtype, device)
+    tcfg = T5Config.from_hf_dict(KNOWN_T5[T0["lm"]])
+    lm = FrozenT5(tcfg, random_init_t5_state_dict(tcfg, 2021, device), dtype, device)      # synthetic weights, as every leg of this bench
+    torch.manual_seed(2021)
+    model = VCT0Prefix(prefix_length=T0["prefix_length"], prefix_size=vcfg.proj, mapping_type="mlp", lm=lm, dtype=dtype, device=device)
+    return vcfg, tcfg, vit, (model.train() if train else model.eval())
+
+
+def _t5_stack_flops(c, enc_pos, dec_pos):
+    """Forward FLOPs per sample of the T5 stacks: 2 x parameters x positions for the projections + 4 S^2 inner per attention."""
+    E, I, F = c.d_model, c.inner, c.d_ff
+    ffn = (3 if c.gated else 2) * E * F
+    enc = c.n_layer * (2 * enc_pos * (4 * E * I + ffn) + 4 * enc_pos * enc_pos * I)
+    dec = c.n_dec_layer * (2 * dec_pos * (6 * E * I + ffn) + 2 * enc_pos * 2 * E * I + 4 * dec_pos * dec_pos * I + 4 * dec_pos * enc_pos * I)
+    return enc, dec
+
+
+def t0_fewshot_qps(dtype, device, reps=3):
+    """Few-shot VQA2 generate with the reference's own model (few_shot_vqa_executor.py:195-205 -> VCT0Model.generate, vct0.py:396-491):
+    32 questions x (4 shots + query), ViT-L/14 encode of 5 images per question, MLP mapper, sentinel expansion, T5 encoder over the 150
+    interleaved positions, cross K / V of 24 decoder layers once, 9 cached greedy decoder steps (max_length 10)."""
+    from eavqa_amd.data.synthetic import fewshot_batch
+    from eavqa_amd.models.t5 import _StepDriver
+    vcfg, c, vit, model = _t0_models(dtype, device, train=False)
+    lm = model.lm
+    B, shots, new = T0["fewshot_batch"], T0["shots"], T0["new_tokens"]
+    n_img = shots + 1
+    b = fewshot_batch(B, c.vocab, shots, T0["seg_len"], 32099, image_size=vcfg.image, device=device)
+    px = b["pixel_values"].reshape(B * n_img, *b["pixel_values"].shape[2:])
+
+    def run():
+        emb = vit.encode_image(px).view(B, n_img, -1)
+        return model.generate(prefix=emb, question_tokens=b["input_ids"], question_mask=b["attention_mask"], num_shots=shots, max_length=new)
+
+    out = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert tuple(out.shape) == (B, new)
+    # phases of one more batch, each bracketed by HIP events on the launch stream behind a head start of queued work
+    blk = torch.randn(8192, 8192, device=device).to(torch.bfloat16)
+    blk_c = torch.empty(8192, 8192, device=device, dtype=torch.bfloat16)
+    for _ in range(40):
+        ops_gemm(blk, blk, out=blk_c)
+    e = [_event()]
+    emb = vit.encode_image(px).view(B, n_img, -1)
+    e.append(_event())
+    rows = model._project(emb)
+    enc, mask, S = model._encode_interleaved(b["input_ids"], b["attention_mask"], rows, n_img, 32099)
+    kv = lm.cross_kv(enc)
+    e.append(_event())
+    t_max = new
+    cache = [(torch.empty((B * t_max, c.inner), device=device, dtype=dtype), torch.empty((B * t_max, c.inner), device=device, dtype=dtype)) for _ in lm.dec]
+    driver = _StepDriver(lm, cache, kv, B, t_max)
+    rel = lm.rel_table(True, t_max)
+    tok = torch.zeros(B, dtype=torch.int64, device=device)
+    for t in range(1, t_max):                         # (the cache buffers and the table are warm; these steps are not timed)
+        driver.step(lm.embed(tok), mask, t, S, rel)
+    e.append(_event())
+    for t in range(1, t_max):                         # a greedy step without the token bookkeeping: embed, 24 decoder layers, lm_head
+        lg = lm.logits(driver.step(lm.embed(tok), mask, t, S, rel))
+    e.append(_event())
+    torch.cuda.synchronize()
+    ms = dict(encode=e[0].elapsed_time(e[1]), t5_encoder=e[1].elapsed_time(e[2]), decode=e[3].elapsed_time(e[4]))
+    W, N = vcfg.width, vcfg.n_patch + 1
+    vit_flop = B * n_img * (vcfg.n_layer * (2 * N * (4 * W * W + 2 * W * vcfg.mlp) + 4 * N * N * W) + 2 * vcfg.n_patch * 3 * vcfg.patch ** 2 * W + 2 * W * vcfg.proj)
+    E, I, F = c.d_model, c.inner, c.d_ff
+    H_map = E * T0["prefix_length"] // 2
+    enc_flop = B * (_t5_stack_flops(c, S, 0)[0] + c.n_dec_layer * 2 * S * 2 * E * I) + B * n_img * 2 * (vcfg.proj * H_map + H_map * E * T0["prefix_length"])
+    steps = new - 1
+    weight_bytes = 2.0 * (c.n_dec_layer * (6 * E * I + (3 if c.gated else 2) * E * F) + E * c.vocab)
+    kv_bytes = 2.0 * c.n_dec_layer * B * S * 2 * I                       # cross K / V of every layer, read once per step (bf16)
+    roof = [
+        dict(phase="vit_encode", bound="mfma", kernel="eavqa_gemm (ViT-L/14 tower) + eavqa_attn_mfma::fwd_resident64", ms=round(ms["encode"], 3),
+             achieved=round(vit_flop / (ms["encode"] * 1e-3) / 1e12, 1), peak=2500.0, unit="TFLOP/s"),
+        dict(phase="mapper_t5_encoder_cross_kv", bound="mfma", kernel="FrozenT5.encode over 150 positions + cross K / V of 24 layers (eavqa_gemm, eavqa_attn_mfma::fwd with relative bias)",
+             ms=round(ms["t5_encoder"], 3), achieved=round(enc_flop / (ms["t5_encoder"] * 1e-3) / 1e12, 1), peak=2500.0, unit="TFLOP/s"),
+        dict(phase="decode", bound="hbm", kernel="eavqa_t5_decoder_step (gemm_bf16_splitk + attn_decode + rms / gated consumers) + lm_head, weights + cross K / V read once per step",
+             ms=round(ms["decode"], 3), ms_per_step=round(ms["decode"] / steps, 3), steps=steps,
+             achieved=round((weight_bytes + kv_bytes) * steps / (ms["decode"] * 1e-3) / 1e9, 1), peak=8000.0, unit="GB/s",
+             bytes_per_step=round(weight_bytes + kv_bytes)),
+    ]
+    for r in roof:
+        r["frac"] = round(r["achieved"] / r["peak"], 4)
+    del model, lm, vit, driver, cache, kv
+    torch.cuda.empty_cache()
+    return {"metric": "fewshot_vqa_questions_per_sec", "value": round(B / dt, 2), "unit": "questions/s", "ms_per_batch": round(dt * 1e3, 2),
+            "config": {"workload": "t0_3b_fewshot: " + T0["desc"] + "; 4 in-context shots + query (5 images / question), 20 text tokens per segment, "
+                                   "150 encoder positions, max_length 10", "batch": B, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "kv_cache": True},
+            "roofline": roof}
+
+
+class _T0TrainModel:
+    """Adapter: ``Stepper`` calls the causal-LM model's keyword signature; ``VCT0Model.forward`` takes (prefix, labels) (vct0.py:380-394)."""
+
+    def __init__(self, model):
+        self.model, self.clip_project = model, model.clip_project
+
+    def __call__(self, *, prefix, labels, **_):
+        return self.model(prefix=prefix, labels=labels)
+
+
+def t0_cc_train_leg(dtype_name, steps, warmup, device, args):
+    """Mapper training on CC-shaped batches through the frozen T0_3B (vct0_exector.py:130-146; the recipe of the reference's
+    README.md:199-209: batch 64, prefix 10, MLP mapper): ViT-L/14 encode -> mapper -> T5 encoder over the 10 prefix positions ->
+    teacher-forced decoder over the caption -> CE -> dgrad through decoder, cross-attention and encoder -> mapper wgrad -> fused AdamW."""
+    from eavqa_amd import ops
+    from eavqa_amd.data.synthetic import cc_batch
+    from eavqa_amd.trainers.data_parallel import GradSync
+    from eavqa_amd.trainers.optim import FusedAdamW
+    dtype = torch.float32 if dtype_name == "f32" else torch.bfloat16
+    vcfg, c, vit, vct0 = _t0_models(dtype, device, train=True)
+    model = _T0TrainModel(vct0)
+    opt = FusedAdamW(vct0.clip_project.flat, lr=1e-4)
+    B = T0["train_batch"]
+    batch = cc_batch(B, c.vocab, c.pad_token_id, image_size=vcfg.image, max_len=T0["text_len"], seed=2021, device="cpu")
+    batch = {k: v.to(device) for k, v in batch.items()}
+    batch["question_lengths"], batch["label_count"] = None, None
+    sync = GradSync(vct0.clip_project.flat.grad, 1, exchange=True)
+    stepper = Stepper(vit, model, opt, batch, c.pad_token_id, sync, overlap_vit=not args.no_overlap)
+    for _ in range(warmup):
+        stepper.step()
+    stepper.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = stepper.step()
+    stepper.flush()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms_per_step = 1e3 * dt / steps
+    roof = step_roofline(vit, model, opt, batch, c.pad_token_id, sync, ops, "t0_3b_cc_train", dtype_name, ms_per_step) if not args.no_roofline else None
+    L, T = T0["prefix_length"], batch["labels"].shape[1]
+    W, N = vcfg.width, vcfg.n_patch + 1
+    vit_f = vcfg.n_layer * (2 * N * (4 * W * W + 2 * W * vcfg.mlp) + 4 * N * N * W) + 2 * vcfg.n_patch * 3 * vcfg.patch ** 2 * W + 2 * W * vcfg.proj
+    E = c.d_model
+    H_map = E * L // 2
+    enc_f, dec_f = _t5_stack_flops(c, L, T)
+    fps = vit_f + 3 * 2 * (vcfg.proj * H_map + H_map * E * L) + 2 * (enc_f + dec_f + 2 * T * E * c.vocab)
+    line = {"metric": "mapper_train_samples_per_sec", "value": round(B * steps / dt, 2), "unit": "samples/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "dtype": dtype_name, "data": "synthetic",
+            "config": {"workload": "t0_3b_cc_train: " + T0["desc"] + f"; per-GPU batch {B}, encoder positions {L}, decoder positions {T}; fwd+bwd+AdamW; "
+                                   "random-init weights", "global_batch": B, "seq_len": L + T, "parallelism": "dp1",
+                       "algorithmic_gflop_per_sample": round(fps / 1e9, 1), "step_tflops": round(B * steps / dt * fps / 1e12, 1),
+                       "final_loss": round(float(loss.item()), 4)},
+            "roofline": roof}
+    del stepper, vit, model, vct0, opt, sync, batch
+    torch.cuda.empty_cache()
+    return line
+
+
 def _event():
     ev = torch.cuda.Event(enable_timing=True)
     ev.record()
@@ -426,6 +590,8 @@ def main():
     ap.add_argument("--no-fewshot", action="store_true", help="skip the few-shot generate leg (metric M2, reported under 'extra')")
     ap.add_argument("--no-extra-train", action="store_true",
                     help="skip the short cfg3 (bf16) and cfg5 (fp8) training legs that the default cfg2 run reports under 'extra'")
+    ap.add_argument("--no-t0", action="store_true",
+                    help="skip the two T0_3B legs (the reference's headline model: few-shot generate and CC mapper training) reported under 'extra'")
     ap.add_argument("--hbm-bytes-out", default=None,
                     help="write the algorithmic bytes per launch of the HBM-bound ops of one step as JSON (input of tools/round_profile_report.py)")
     args = ap.parse_args()
@@ -470,6 +636,15 @@ def main():
                 extra.append(train_leg(name, dt_name, k, wu, rank, world, device, leg_args, log_prefix=f"[{name} {dt_name}] "))
             except Exception as e:
                 extra.append({"metric": "mapper_train_samples_per_sec", "config": {"workload": name}, "dtype": dt_name, "error": repr(e)[:300]})
+                torch.cuda.empty_cache()
+    if solo and not args.no_t0 and args.workload == "cfg2" and args.dtype == "bf16" and not args.mapping_type:
+        for name, fn in (("t0_3b_fewshot", lambda: t0_fewshot_qps(dtype, device)), ("t0_3b_cc_train", lambda: t0_cc_train_leg("bf16", 10, 5, device, args))):
+            try:
+                log(f"{name} leg ...")
+                extra.append(fn())
+                log(f"{name} leg done: {extra[-1]}")
+            except Exception as e:
+                extra.append({"metric": name, "error": repr(e)[:300]})
                 torch.cuda.empty_cache()
     cpu = None
     if solo and args.cpu_baseline_samples > 0:
