@@ -274,9 +274,11 @@ class FrozenT5:
         """K | V of every decoder layer's cross-attention over the encoder output (computed once per generation)."""
         return [ops.gemm(enc_out, b.w_kv_ca) for b in self.dec]
 
-    def decode(self, y: Tensor, enc_out: Tensor, enc_mask: Tensor, B: int, Td: int, S: int, save: bool = False, kv: Optional[List[Tensor]] = None):
-        """Teacher-forced / re-forward decoder over ``Td`` positions: ``y`` float32 [B*Td, E] decoder input embeddings.  Returns (final
-        hidden rows in the compute dtype [B*Td, E], tape)."""
+    def decode(self, y: Tensor, enc_out: Tensor, enc_mask: Tensor, B: int, Td: int, S: int, save: bool = False, kv: Optional[List[Tensor]] = None,
+               dec_mask: Optional[Tensor] = None):
+        """Teacher-forced / re-forward decoder over ``Td`` positions: ``y`` float32 [B*Td, E] decoder input embeddings.  ``dec_mask`` (int32
+        [B, Td], generation with a padded decoder prompt only): 0 = a key the self-attention must not see (HF's ``decoder_attention_mask``;
+        positions stay absolute, as in HF).  Returns (final hidden rows in the compute dtype [B*Td, E], tape)."""
         c, T = self.cfg, self.dtype
         I, H, dkv = c.inner, c.n_head, c.d_kv
         rel, zero = self.rel_table(True, Td)
@@ -286,7 +288,7 @@ class FrozenT5:
             a, r1 = ops.rmsnorm_fwd(x, b.ln_sa, c.eps, T, save_stats=True)
             qkv = ops.gemm(a, b.w_qkv)
             ctx, lse = ops.attention_fwd_rel(qkv[:, :I], qkv[:, I:2 * I], qkv[:, 2 * I:], B, H, Td, Td, dkv, rel_bias=rel, rel_zero=zero,
-                                             causal=True, scale=1.0, save_lse=True)
+                                             key_mask=dec_mask, causal=True, scale=1.0, save_lse=True)
             x1 = ops.gemm(ctx, b.w_o, residual=x, out_f32=True)
             ac, rc = ops.rmsnorm_fwd(x1, b.ln_ca, c.eps, T, save_stats=True)
             qc = ops.gemm(ac, b.w_q_ca)
@@ -470,7 +472,7 @@ class FrozenT5:
     # ---------------------------------------------------------------- greedy generation
     @torch.no_grad()
     def greedy(self, enc_out: Tensor, enc_mask: Tensor, B: int, S: int, max_length: int, dec_prompt: Optional[Tensor] = None,
-               output_scores: bool = False, use_cache: bool = True):
+               output_scores: bool = False, use_cache: bool = True, dec_mask: Optional[Tensor] = None):
         """HF greedy search for an encoder-decoder: start = decoder_start_token_id, a row that produced eos emits pad afterwards, stop
         when every row is finished or ``max_length`` decoder positions exist.  The cross-attention K / V of every layer are computed
         once; a step runs the decoder on the newest position against a self-attention K / V cache (``use_cache``; with a multi-token
@@ -478,7 +480,19 @@ class FrozenT5:
         ``(sequences int64 [B, <= max_length] on the host, [per-step logits float32 [B, V] on the host] | None)``."""
         c = self.cfg
         kv = self.cross_kv(enc_out)
-        start = torch.full((B, 1), c.decoder_start_token_id, dtype=torch.int64, device=self.device) if dec_prompt is None else dec_prompt.to(self.device)
+        start = torch.full((B, 1), c.decoder_start_token_id, dtype=torch.int64, device=self.device)
+        dkey = None
+        if dec_prompt is not None:
+            # HF ``_prepare_decoder_input_ids_for_generation``: a prompt of which NO row begins with the decoder start id gets it prepended
+            # (and its mask a column of ones); a left-padded prompt (pad id == start id for T5, module_parser.py:397-399) is taken as is
+            prompt = dec_prompt.to(self.device)
+            pm = dec_mask.to(self.device) if dec_mask is not None else torch.ones_like(prompt)
+            if bool((prompt[:, 0] != c.decoder_start_token_id).all()):
+                prompt, pm = torch.cat([start, prompt], dim=1), torch.cat([torch.ones_like(pm[:, :1]), pm], dim=1)
+            start = prompt
+            if not bool((pm != 0).all()):
+                dkey = torch.ones((B, max(max_length, start.shape[1])), dtype=torch.int32, device=self.device)
+                dkey[:, :start.shape[1]] = (pm != 0).to(torch.int32)
         P = start.shape[1]
         seq = torch.full((B, max(max_length, P)), c.pad_token_id, dtype=torch.int64, device=self.device)
         seq[:, :P] = start
@@ -506,7 +520,7 @@ class FrozenT5:
                 last = self.decode_step(self.embed(seq[:, t - 1].contiguous()), cache, enc_mask, B, t, S, kv, t_max, rel_gen)
             else:
                 y = self.embed(seq[:, :t].contiguous())
-                hid, _ = self.decode(y, enc_out, enc_mask, B, t, S, kv=kv)
+                hid, _ = self.decode(y, enc_out, enc_mask, B, t, S, kv=kv, dec_mask=dkey[:, :t].contiguous() if dkey is not None else None)
                 last = hid.view(B, t, c.d_model)[:, -1].contiguous()
             lg = self.logits(last)
             if output_scores:

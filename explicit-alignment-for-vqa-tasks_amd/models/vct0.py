@@ -145,8 +145,6 @@ class VCT0Model(nn.Module):
                        or (k == "do_sample" and v)}
         if unsupported:
             raise NotImplementedError(f"greedy search only; unsupported generation arguments: {sorted(unsupported)}")
-        if decoder_attention_mask is not None and not bool((decoder_attention_mask != 0).all()):
-            raise NotImplementedError("a padded decoder prompt is not supported")
         finish = lambda seq, scores: _GenerateOutput(seq, scores) if return_dict_in_generate else seq
         tok = question_tokens.to(dev) if question_tokens is not None else None
         qm = question_mask.to(dev) if question_mask is not None else (torch.ones_like(tok) if tok is not None else None)
@@ -182,7 +180,9 @@ class VCT0Model(nn.Module):
             return finish(*lm.greedy(enc.reshape(B * S, E).contiguous(), mask, B, S, max_length, output_scores=output_scores, use_cache=use_cache))
         if decoder_input_ids is not None:                                  # :468-480: only the query image, the decoder continues a prompt
             enc, mask, S = self._encode_interleaved(tok, qm, rows.view(B, n_img, L, -1)[:, -1].reshape(B * L, -1).contiguous(), 1, special_token_id)
-            seq, scores = lm.greedy(enc, mask, B, S, max_length, dec_prompt=decoder_input_ids, output_scores=output_scores, use_cache=use_cache)
+            seq, scores = lm.greedy(enc, mask, B, S, max_length, dec_prompt=decoder_input_ids, output_scores=output_scores, use_cache=use_cache,
+                                    dec_mask=decoder_attention_mask)
+            # (the reference slices by the prompt length it was GIVEN: when HF prepended the start token the prompt's last token stays in)
             return finish(seq[:, decoder_input_ids.shape[1]:], scores)
         ns = (n_img - 1) if not num_shots else num_shots
         enc, mask, S = self._encode_interleaved(tok, qm, rows, ns + 1, special_token_id)

@@ -511,9 +511,10 @@ def t5_encoder(sd, cfg: dict, inputs_embeds: Tensor, attention_mask: Optional[Te
     return t5_rms_norm(h, sd["encoder.final_layer_norm.weight"], eps)
 
 
-def t5_decoder(sd, cfg: dict, dec_embeds: Tensor, enc_out: Tensor, enc_mask: Optional[Tensor] = None) -> Tensor:
+def t5_decoder(sd, cfg: dict, dec_embeds: Tensor, enc_out: Tensor, enc_mask: Optional[Tensor] = None, dec_mask: Optional[Tensor] = None) -> Tensor:
     """``T5Stack`` (decoder): causal self-attention with the unidirectional relative bias of block 0, cross-attention over the encoder
-    output (zero position bias, encoder padding masked), FFN; final RMSNorm."""
+    output (zero position bias, encoder padding masked), FFN; final RMSNorm.  ``dec_mask`` [B, T] (HF ``decoder_attention_mask``, a padded
+    decoder prompt): 0 = a key the self-attention does not see; positions stay absolute."""
     B, T, _ = dec_embeds.shape
     S = enc_out.shape[1]
     H, dkv, eps = cfg["n_head"], cfg["d_kv"], cfg.get("eps", 1e-6)
@@ -523,6 +524,8 @@ def t5_decoder(sd, cfg: dict, dec_embeds: Tensor, enc_out: Tensor, enc_mask: Opt
     self_bias = t5_position_bias(sd["decoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], T, T, False,
                                  max_distance=cfg.get("max_distance", 128))
     self_bias = self_bias + torch.where(torch.ones(T, T, dtype=torch.bool).tril()[None, None], 0.0, NEG)
+    if dec_mask is not None:
+        self_bias = self_bias + torch.where(dec_mask[:, None, None, :] != 0, 0.0, NEG)
     cross_bias = torch.where(enc_mask[:, None, None, :] != 0, 0.0, NEG).expand(B, 1, T, S)
     h = dec_embeds
     for i in range(n_dec):
@@ -561,21 +564,31 @@ def vct0_forward(sd, cfg: dict, mapper, mcfg: dict, prefix: Tensor, labels: Tens
     return loss, logits
 
 
-def _t5_greedy(sd, cfg: dict, enc: Tensor, enc_mask: Optional[Tensor], max_length: int, dec_prompt: Optional[Tensor] = None):
+def _t5_greedy(sd, cfg: dict, enc: Tensor, enc_mask: Optional[Tensor], max_length: int, dec_prompt: Optional[Tensor] = None,
+               dec_mask: Optional[Tensor] = None):
     """HF greedy search for an encoder-decoder (``GenerationMixin._sample`` with do_sample=False): start token = decoder_start_token_id
     (= pad = 0 for T5), every step re-runs the decoder over the whole prefix (same logits as the cached run), rows that produced eos (1)
-    emit pad afterwards, stop when all rows are finished or ``max_length`` TOTAL decoder positions exist.  Returns
-    ``(sequences [B, <= max_length], per-step logits list)``."""
+    emit pad afterwards, stop when all rows are finished or ``max_length`` TOTAL decoder positions exist.  A decoder prompt
+    (``_prepare_decoder_input_ids_for_generation``): the start token is prepended - and the mask extended by a column of ones - only when NO
+    row of the prompt begins with it; generated positions are attended (mask 1).  Returns ``(sequences [B, <= max_length], per-step logits list)``."""
     B = enc.shape[0]
     start, pad, eos = cfg.get("decoder_start_token_id", 0), cfg.get("pad_token_id", 0), cfg.get("eos_token_id", 1)
-    seq = torch.full((B, 1), start, dtype=torch.long) if dec_prompt is None else dec_prompt.clone()
+    seq = torch.full((B, 1), start, dtype=torch.long)
+    dmask = None
+    if dec_prompt is not None:
+        dmask = dec_mask.clone() if dec_mask is not None else torch.ones_like(dec_prompt)
+        if bool((dec_prompt[:, 0] != start).all()):
+            dec_prompt, dmask = torch.cat([seq, dec_prompt], dim=1), torch.cat([torch.ones_like(dmask[:, :1]), dmask], dim=1)
+        seq = dec_prompt.clone()
     unfinished = torch.ones(B, dtype=torch.long)
     scores = []
     while seq.shape[1] < max_length:
-        logits = t5_lm_logits(sd, cfg, t5_decoder(sd, cfg, sd["shared.weight"][seq], enc, enc_mask))[:, -1]
+        logits = t5_lm_logits(sd, cfg, t5_decoder(sd, cfg, sd["shared.weight"][seq], enc, enc_mask, dmask))[:, -1]
         scores.append(logits)
         nxt = logits.argmax(-1) * unfinished + pad * (1 - unfinished)
         seq = torch.cat([seq, nxt[:, None]], dim=1)
+        if dmask is not None:
+            dmask = torch.cat([dmask, torch.ones_like(dmask[:, :1])], dim=1)
         unfinished = unfinished * (nxt != eos).long()
         if unfinished.max() == 0:
             break
@@ -584,14 +597,17 @@ def _t5_greedy(sd, cfg: dict, enc: Tensor, enc_mask: Optional[Tensor], max_lengt
 
 def vct0_generate(sd, cfg: dict, mapper, mcfg: dict, prefix: Tensor, question_tokens: Optional[Tensor] = None,
                   question_mask: Optional[Tensor] = None, num_shots: Optional[int] = None, max_length: int = 20,
-                  special_token_id: int = 32099, one_at_a_time: bool = False, no_prefix: bool = False):
+                  special_token_id: int = 32099, one_at_a_time: bool = False, no_prefix: bool = False,
+                  decoder_input_ids: Optional[Tensor] = None, decoder_attention_mask: Optional[Tensor] = None):
     """``VCT0Model.generate`` src/models/vct0.py:396-491 (greedy, HF defaults):
       * ``question_tokens is None`` (:485-491, the CC executor): the encoder sees the projected prefix only;
       * few-shot (:452-466): sentinel tokens ``special_token_id - i`` of the prompt are replaced by the L prefix vectors of image i
         (``insert_prefix_into_input`` :494-533), one encoder pass over the joint sequence;
       * ``one_at_a_time`` (:426-442): question_tokens ``[B, n, T]``; example i is encoded by itself with sentinel ``special - i``, the
         encoder outputs and masks are concatenated along the sequence before decoding;
-      * ``no_prefix`` (:409-424, text only): plain T5 generate on the tokens.
+      * ``no_prefix`` (:409-424, text only): plain T5 generate on the tokens;
+      * ``decoder_input_ids`` (:468-480): the encoder sees the LAST image's prefix at the one sentinel of each row, the decoder continues the
+        prompt; the sequences are cut by the GIVEN prompt length, as the reference does.
     Returns ``(sequences, scores)``."""
     E, L = sd["shared.weight"].shape[1], mcfg["prefix_length"]
     proj = lambda p: mapper_project(p, mapper, mcfg.get("mapping_type", "mlp"), L, E, mcfg.get("clip_length"), mcfg.get("num_layers", 8))
@@ -615,5 +631,9 @@ def vct0_generate(sd, cfg: dict, mapper, mcfg: dict, prefix: Tensor, question_to
     n_img = prefix.shape[1] if prefix.dim() >= 3 else 1
     ns = (n_img - 1) if not num_shots else num_shots
     pp = proj(prefix.reshape(-1, prefix.shape[-1])).view(B, -1, L, E)
+    if decoder_input_ids is not None:
+        emb, msk = insert_prefix_into_input(L, 0, question_tokens, sd["shared.weight"][question_tokens], pp[:, -1], question_mask, special_token_id)
+        seq, scores = _t5_greedy(sd, cfg, t5_encoder(sd, cfg, emb, msk), msk, max_length, decoder_input_ids, decoder_attention_mask)
+        return seq[:, decoder_input_ids.shape[1]:], scores
     emb, msk = insert_prefix_into_input(L, ns, question_tokens, sd["shared.weight"][question_tokens], pp, question_mask, special_token_id)
     return _t5_greedy(sd, cfg, t5_encoder(sd, cfg, emb, msk), msk, max_length)

@@ -388,6 +388,28 @@ def vct0_golden():
         with torch.no_grad():
             o = model.generate(prefix=pf, question_tokens=q, question_mask=qm, no_prefix=True, **kw)
         arrs.update(gen_text_ids=o.sequences.numpy(), gen_text_scores=torch.stack(o.scores).numpy())
+        # ---- generate: decoder prompt (vct0.py:468-480, fed by few_shot_vqa_executor.py:205-206): the encoder sees the query image's prefix only
+        #      (ONE sentinel per row), the decoder continues a prompt.  (a) no row starts with the decoder start id: HF prepends it, and the
+        #      reference's `outputs[:, decoder_input_ids.shape[1]:]` then keeps the prompt's last token; (b) left-padded prompts as the reference
+        #      tokenises them (module_parser.py:397-399): pad id == start id, so HF prepends nothing, the pads are masked keys.
+        #      (plain sequences: the reference slices the output, which a return_dict_in_generate object does not support)
+        Td = 8
+        qd = torch.randint(2, V - 8, (B, Td), generator=gen)
+        qd[:, 2] = V - 1
+        qmd = torch.ones(B, Td, dtype=torch.long)
+        qmd[2, Td - 1] = 0
+        qd[2, Td - 1] = 0
+        dec_a = torch.randint(2, V - 8, (B, 3), generator=gen)
+        dec_b = torch.randint(2, V - 8, (B, 3), generator=gen)
+        dec_b_mask = torch.ones(B, 3, dtype=torch.long)
+        dec_b[1, :2], dec_b_mask[1, :2] = 0, 0
+        dec_b[2, :1], dec_b_mask[2, :1] = 0, 0
+        kw2 = dict(max_length=9, do_sample=False, num_beams=1)
+        with torch.no_grad():
+            oa = model.generate(prefix=pf, question_tokens=qd, question_mask=qmd, decoder_input_ids=dec_a, decoder_attention_mask=torch.ones_like(dec_a), **kw2)
+            ob = model.generate(prefix=pf, question_tokens=qd, question_mask=qmd, decoder_input_ids=dec_b, decoder_attention_mask=dec_b_mask, **kw2)
+        arrs.update(dp_tokens=qd.numpy(), dp_mask=qmd.numpy(), dp_dec_a=dec_a.numpy(), dp_dec_b=dec_b.numpy(), dp_dec_b_mask=dec_b_mask.numpy(),
+                    gen_dp_a_ids=oa.numpy(), gen_dp_b_ids=ob.numpy())
         save(f"vct0_{tag}.npz", **arrs)
     shutil.rmtree(tmp, ignore_errors=True)
 

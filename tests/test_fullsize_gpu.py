@@ -104,9 +104,11 @@ def _hip_train(cfg, sd, vit_name, vsd, dtype, b, L, mapper_sd=None, pack=True):
 BF16_TOL = dict(logits=8e-2, loss=1e-2, grad=4e-2, emb=3e-2)
 
 
-@pytest.mark.parametrize("name,vit_name,lm_name,B", [("cfg2", "ViT-B/32", "gpt2-large", 4), ("cfg3", "ViT-L/14", "facebook/opt-1.3b", 2)])
+@pytest.mark.parametrize("name,vit_name,lm_name,B", [("cfg1", "ViT-B/32", "gpt2", 4), ("cfg2", "ViT-B/32", "gpt2-large", 4),
+                                                     ("cfg3", "ViT-L/14", "facebook/opt-1.3b", 2)])
 def test_training_step_real_size_matches_oracle(name, vit_name, lm_name, B):
-    """ViT encode -> mapper -> LM -> shifted CE -> backward into the mapper at the configuration's real depth and width."""
+    """ViT encode -> mapper -> LM -> shifted CE -> backward into the mapper at the configuration's real depth and width (cfg1 = BASELINE
+    configs[0], the reference's CPU-runnable case at its own batch of 4: 12 layers, E = 768)."""
     from eavqa_amd.models.clip_vit import KNOWN_VITS, random_init_vit_state_dict
     L = 10
     cfg, sd, b = _train_case(vit_name, lm_name, B, seed=31)

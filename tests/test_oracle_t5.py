@@ -50,6 +50,20 @@ def test_vct0_generate_paths_match_reference(tag):
         assert got.shape == want_scores.shape and (got - want_scores).abs().max().item() <= 5e-5, name
 
 
+@pytest.mark.parametrize("tag", ["t0", "t5v10"])
+def test_vct0_generate_decoder_prompt_matches_reference(tag):
+    """The decoder-prompt branch (vct0.py:468-480) on the reference's own outputs: a prompt HF prepends the start token to, and a left-padded
+    prompt with its mask (module_parser.py:397-399)."""
+    z, T, sd, cfg, mapper, mcfg, V = _case(tag)
+    kw = dict(max_length=9, special_token_id=V - 1)
+    with torch.no_grad():
+        a, _ = oracle.vct0_generate(sd, cfg, mapper, mcfg, T(z["fs_prefix"]), T(z["dp_tokens"]), T(z["dp_mask"]), decoder_input_ids=T(z["dp_dec_a"]),
+                                    decoder_attention_mask=torch.ones_like(T(z["dp_dec_a"])), **kw)
+        b, _ = oracle.vct0_generate(sd, cfg, mapper, mcfg, T(z["fs_prefix"]), T(z["dp_tokens"]), T(z["dp_mask"]), decoder_input_ids=T(z["dp_dec_b"]),
+                                    decoder_attention_mask=T(z["dp_dec_b_mask"]), **kw)
+    assert torch.equal(a, T(z["gen_dp_a_ids"])) and torch.equal(b, T(z["gen_dp_b_ids"]))
+
+
 def test_t5_relative_buckets_known_values():
     """Spot values of T5's bucket function (HF:models/t5/modeling_t5.py:217-262): exact buckets below 8 (bidirectional) / 16 (causal),
     logarithmic beyond, the sign in the upper half for the bidirectional case."""

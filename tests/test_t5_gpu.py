@@ -334,15 +334,27 @@ def test_vct0_generate_stops_early_like_hf_greedy(tag):
     assert stopped_early >= 1                            # the case this test exists for did occur
 
 
-def test_vct0_prefix_trains_only_the_mapper_and_decoder_prompt_path():
+def test_vct0_prefix_trains_only_the_mapper():
     z, T, model, V = _model("t0", torch.float32)
     names = {n for n, _ in model.clip_project.named_parameters()}
     assert {id(p) for p in model.parameters()} == {id(p) for p in model.clip_project.parameters()} and names
+
+
+@pytest.mark.parametrize("tag", ["t0", "t5v10"])
+def test_vct0_generate_decoder_prompt_matches_reference_ids(tag):
+    """``VCT0Model.generate(decoder_input_ids=..., decoder_attention_mask=...)`` (vct0.py:468-480) against the reference's own output
+    (tests/golden/make_golden.py --vct0-only): (a) a prompt no row of which begins with the decoder start id - HF prepends it and the
+    reference's slice by the GIVEN prompt length keeps the prompt's last token; (b) a LEFT-PADDED prompt as the reference tokenises decoder
+    prompts (module_parser.py:397-399): pad id == start id, nothing prepended, the pads are masked keys of the decoder self-attention."""
+    z, T, model, V = _model(tag, torch.float32)
     model.eval()
-    prompt = torch.tensor([[0, 5, 6]] * 3)
-    o = model.generate(prefix=T(z["fs_prefix"]), question_tokens=T(z["one_tokens"])[:, 0].contiguous() * 0 + T(z["one_tokens"])[:, 0],
-                       question_mask=T(z["one_mask"])[:, 0], decoder_input_ids=prompt, special_token_id=V - 1, max_length=8)
-    assert o.shape[0] == 3 and o.shape[1] <= 8 - 3
+    kw = dict(prefix=T(z["fs_prefix"]), question_tokens=T(z["dp_tokens"]), question_mask=T(z["dp_mask"]), special_token_id=V - 1, max_length=9)
+    a = model.generate(decoder_input_ids=T(z["dp_dec_a"]), decoder_attention_mask=torch.ones_like(T(z["dp_dec_a"])), **kw)
+    assert a.tolist() == z["gen_dp_a_ids"].tolist()
+    b = model.generate(decoder_input_ids=T(z["dp_dec_b"]), decoder_attention_mask=T(z["dp_dec_b_mask"]), **kw)
+    assert b.tolist() == z["gen_dp_b_ids"].tolist()
+    # the padded mask matters: ignoring it changes what the decoder attends to (at least the scores; the tiny model's ids may coincide)
+    assert model.generate(decoder_input_ids=T(z["dp_dec_b"]), **kw).shape == b.shape
 
 
 def test_vct0_executors_from_config_train_and_generate():
