@@ -54,7 +54,7 @@ SIGNATURES = {
     "eavqa_ce_fwd": [i32, i32, i32, ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr],
     "eavqa_guard_count": [ptr, i32, ptr, ptr],
     "eavqa_ce_bwd": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr],
-    "eavqa_greedy_pick": [i32, i32, ptr, i64, i64, i64, ptr, ptr, i64, ptr, ptr, ptr],
+    "eavqa_greedy_pick": [i32, i32, ptr, i64, i64, i64, ptr, ptr, i64, ptr, ptr, ptr, ptr],
     "eavqa_adamw": [i64, ptr, ptr, ptr, ptr, i32, f32, f32, f32, f32, f32, f32, i32, ptr, ptr],
     "eavqa_patchify": [i32, i32, i32, i32, ptr, ptr, i64, ptr],
     "eavqa_vit_assemble": [i32, i32, i32, i32, ptr, i64, ptr, ptr, ptr, i64, ptr],

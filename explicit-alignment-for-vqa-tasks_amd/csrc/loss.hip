@@ -157,7 +157,7 @@ constexpr int GP_THREADS = 1024;
 
 __global__ __launch_bounds__(GP_THREADS) void greedy_pick_kernel(int V, const float* logits, int64_t ld, int64_t pad, int64_t eos,
                                                           int32_t* raw, int64_t* emitted, int64_t ld_emitted,
-                                                          int32_t* unfinished, float* logprob) {
+                                                          int32_t* unfinished, float* logprob, int32_t* any_unfinished) {
     __shared__ float sv[GP_THREADS];
     __shared__ int si[GP_THREADS];
     const int b = blockIdx.x;
@@ -185,7 +185,11 @@ __global__ __launch_bounds__(GP_THREADS) void greedy_pick_kernel(int V, const fl
         if (eos >= 0) {                          // clipcap.py:426-434 (finished rows emit pad)
             const int u = unfinished[b];
             e = u ? (int64_t)r : pad;
-            unfinished[b] = u * (e != eos ? 1 : 0);   // :458-461
+            const int u2 = u * (e != eos ? 1 : 0);    // :458-461
+            unfinished[b] = u2;
+            // "some row is still generating" for the host's early-stop check (:463), without a reduction kernel: the caller zeroes the
+            // word, every row that goes on ORs a one into it (idempotent: no order dependence)
+            if (any_unfinished && u2) atomicOr(any_unfinished, 1);
         }
         emitted[(int64_t)b * ld_emitted] = e;
     }
@@ -245,12 +249,12 @@ extern "C" int eavqa_ce_bwd(int dtype, int B, int S, int V, const float* logits,
 
 extern "C" int eavqa_greedy_pick(int B, int V, const float* logits, int64_t ld, int64_t pad_token_id, int64_t eos_token_id,
                                  int32_t* raw, int64_t* emitted, int64_t ld_emitted, int32_t* unfinished, float* logprob,
-                                 void* stream) {
+                                 int32_t* any_unfinished, void* stream) {
     if (B <= 0 || V <= 0 || !logits || !raw || !emitted) return EAVQA_E_ARG;
     if (eos_token_id >= 0 && !unfinished) return EAVQA_E_ARG;
     if (ld < V) return EAVQA_E_ARG;
     hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(GP_THREADS), 0, reinterpret_cast<hipStream_t>(stream), V, logits, ld,
-                       pad_token_id, eos_token_id, raw, emitted, ld_emitted, unfinished, logprob);
+                       pad_token_id, eos_token_id, raw, emitted, ld_emitted, unfinished, logprob, any_unfinished);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }

@@ -47,7 +47,7 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
     unfinished = torch.ones(B, dtype=torch.int32, device=dev)
     logp = torch.zeros((max_length, B), dtype=torch.float32, device=dev) if output_scores else None
     produced = 0
-    alive = torch.ones(max_length, dtype=torch.int32, device=dev)      # alive[t]: some row still unfinished after step t
+    alive = torch.zeros(max_length, dtype=torch.int32, device=dev)     # alive[t]: some row still unfinished after step t (set by the pick kernel)
     if use_cache:
         cache = _KVCache(lm, B, S_max, B * S0)
         logits = _prefill(lm, cache, prefix_rows, src[:, :S0].contiguous(), pos[:, :S0].contiguous(), mask, B, S0, S_max)
@@ -58,14 +58,13 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
             logits = lm.forward(prefix_rows, src[:, :S].contiguous(), pos[:, :S].contiguous(), mask[:, :S].contiguous(),
                                 B, S, logits="last")["logits"]
         ops.greedy_pick(logits, lm.vocab, pad_token_id, eos_token_id, raw, tokens[:, t], unfinished,
-                        logp[t] if output_scores else None)
+                        logp[t] if output_scores else None, alive[t:t + 1] if eos_token_id is not None else None)
         produced = t + 1
         src[:, S0 + t] = raw                                   # the RAW argmax is what gets embedded (clipcap.py:423)
         if eos_token_id is not None:
             # clipcap.py:463 stops when every row has finished.  The host reads the flag every fourth step only (a device -> host round
             # trip per step would leave the launch queue empty while the next step is being enqueued); steps run past the stop emit pad
             # and are cut off below, so the ids are those of a check after every step.
-            torch.amax(unfinished, dim=0, out=alive[t])
             if (t + 1) % 4 == 0 and int(alive[t].item()) == 0:
                 break
         if t + 1 < max_length and use_cache:

@@ -502,7 +502,7 @@ class FrozenT5:
         # `alive[t]` = some row still unfinished after position t was written.  The host looks at it every fourth step only (one
         # device -> host round trip per step would keep the launch queue empty); positions written after every row had finished hold
         # pad and are cut off below, so the result is the one of a check after every step.
-        alive = torch.ones(max(max_length, P) + 1, dtype=torch.int32, device=self.device)
+        alive = torch.zeros(max(max_length, P) + 1, dtype=torch.int32, device=self.device)     # written by the pick kernel (eavqa_greedy_pick)
         cached = use_cache and P == 1 and max_length > 1
         if cached:
             t_max = max_length
@@ -525,8 +525,8 @@ class FrozenT5:
             lg = self.logits(last)
             if output_scores:
                 scores.append(lg[:, :c.vocab].float())
-            ops.greedy_pick(lg, c.vocab, c.pad_token_id, c.eos_token_id, raw, seq[:, t], unfinished)      # emitted token = what is fed back
-            torch.amax(unfinished, dim=0, out=alive[t])
+            ops.greedy_pick(lg, c.vocab, c.pad_token_id, c.eos_token_id, raw, seq[:, t], unfinished,      # emitted token = what is fed back
+                            any_unfinished=alive[t:t + 1])
             t += 1
             if (t - P) % 4 == 0 and int(alive[t - 1].item()) == 0:
                 break

@@ -331,12 +331,13 @@ def ce_bwd(logits: Tensor, labels: Tensor, V: int, row_lse: Tensor, count: Tenso
 
 
 def greedy_pick(logits: Tensor, V: int, pad_token_id: int, eos_token_id: Optional[int], raw: Tensor, emitted_col: Tensor,
-                unfinished: Tensor, logprob: Optional[Tensor] = None) -> None:
-    """``emitted_col``: int64 view [B] of column t of the [B, max_length] token matrix; ``logprob``: float32 [B] or None."""
+                unfinished: Tensor, logprob: Optional[Tensor] = None, any_unfinished: Optional[Tensor] = None) -> None:
+    """``emitted_col``: int64 view [B] of column t of the [B, max_length] token matrix; ``logprob``: float32 [B] or None;
+    ``any_unfinished``: a ZEROED int32 element that reads 1 afterwards when some row is still unfinished (the early-stop flag)."""
     B = logits.shape[0]
     call("eavqa_greedy_pick", B, V, _p(logits), _ld(logits), int(pad_token_id if pad_token_id is not None else 0),
          int(eos_token_id) if eos_token_id is not None else -1, _p(raw), _p(emitted_col), emitted_col.stride(0),
-         _p(unfinished), _p(logprob), _stream())
+         _p(unfinished), _p(logprob), _p(any_unfinished), _stream())
 
 
 def adamw(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float = 0.9, beta2: float = 0.999,

@@ -245,9 +245,12 @@ int eavqa_ce_bwd(int dtype, int B, int S, int V, const float* logits, int64_t ld
  * finished-row bookkeeping of :426-461: raw[b] = argmax; emitted[b] = unfinished ? raw : pad;
  * unfinished[b] &= (emitted != eos) when eos >= 0.  logits float32 [B, ld].
  * logprob (NULL = skip): float32 [B], log_softmax(logits[b])[raw[b]] - the per-token score that the few-shot
- * ensembling sums (`torch.log(torch.stack(outputs.scores).softmax(-1))`, src/trainers/few_shot_vqa_executor.py:314). */
+ * ensembling sums (`torch.log(torch.stack(outputs.scores).softmax(-1))`, src/trainers/few_shot_vqa_executor.py:314).
+ * any_unfinished (NULL = skip; eos >= 0 only): one int32 the caller has zeroed; set to 1 when some row is still unfinished after this
+ * step - the `unfinished_sequences.max() == 0` test of clipcap.py:463 without a reduction on the host side of the ABI. */
 int eavqa_greedy_pick(int B, int V, const float* logits, int64_t ld, int64_t pad_token_id, int64_t eos_token_id,
-                      int32_t* raw, int64_t* emitted, int64_t ld_emitted, int32_t* unfinished, float* logprob, void* stream);
+                      int32_t* raw, int64_t* emitted, int64_t ld_emitted, int32_t* unfinished, float* logprob,
+                      int32_t* any_unfinished, void* stream);
 
 /* ----------------------------------------------------------- optimiser ---
  * torch.optim.AdamW single-tensor update as configured at src/trainers/clipcap_exector.py:79-81

@@ -740,10 +740,15 @@ def test_greedy_pick_first_max_and_finished_rows(ops):
     raw = torch.empty(B, dtype=torch.int32, device=DEV)
     toks = torch.zeros(B, 6, dtype=torch.int64, device=DEV)
     unf = torch.tensor([1, 1, 0, 1], dtype=torch.int32, device=DEV)
-    ops.greedy_pick(logits.to(DEV), V, 42, 999, raw, toks[:, 2], unf)
+    alive = torch.zeros(3, dtype=torch.int32, device=DEV)
+    ops.greedy_pick(logits.to(DEV), V, 42, 999, raw, toks[:, 2], unf, any_unfinished=alive[0:1])
     assert raw.cpu().tolist() == [17, 999, 5, 0]
     assert toks[:, 2].cpu().tolist() == [17, 999, 42, 0]     # finished row emits pad (clipcap.py:431-434)
     assert unf.cpu().tolist() == [1, 0, 0, 1]                # row 1 just produced eos (clipcap.py:458-461)
+    # the early-stop flag (clipcap.py:463): some row unfinished -> 1; every row finished (eos = what rows 0 and 3 emit) -> stays 0
+    unf2 = torch.tensor([1, 0, 0, 0], dtype=torch.int32, device=DEV)
+    ops.greedy_pick(logits.to(DEV), V, 42, 17, raw, toks[:, 4], unf2, any_unfinished=alive[1:2])
+    assert alive.cpu().tolist() == [1, 0, 0] and unf2.cpu().tolist() == [0, 0, 0, 0]
     ops.greedy_pick(logits.to(DEV), V, 42, None, raw, toks[:, 3], unf)   # eos None: raw tokens, flags untouched
     lp = torch.empty(logits.shape[0], device=DEV)
     ops.greedy_pick(logits.to(DEV), V, 42, None, raw, toks[:, 3], unf, lp)

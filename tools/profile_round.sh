@@ -5,15 +5,42 @@
 #   3. rocprofv3 --pmc WRITE_SIZE                 -> gpurun_out/prof_<tag>/write
 #   4. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES
 # The program goes directly after `--` (no env / bash -c hop).  Usage: tools/profile_round.sh <tag> [bench args...]
+#
+#   tools/profile_round.sh --all <round>    the whole round's evidence in one call (what the lettered one-off scripts of round 3 fed):
+#       cfg2 bf16 and cfg5 fp8 through the four passes above, summarised ON the box by tools/round_profile_report.py (the raw per-dispatch
+#       CSVs are hundreds of MiB; only the summaries travel back), then the kernel statistics of the few-shot generate run (OPT-2.7B) and
+#       of the T0_3B few-shot tool.  Results: gpurun_out/<round>_profiles/ - copy what is to be judged into profiles/.
+if [ "$1" = "--all" ]; then
+  R=${2:-round}
+  cd ${GRAFT_REPO_ROOT:-.}
+  S=gpurun_out/${R}_profiles; mkdir -p $S
+  for W in "cfg2 bf16" "cfg5 fp8"; do
+    set -- $W
+    tag=${R}_$1
+    extra=""; [ "$1" != "cfg2" ] && extra="--workload $1 --dtype $2"
+    bash tools/profile_round.sh $tag $extra > gpurun_out/prof_$tag.log 2>&1; echo "$tag profiled rc=$?"
+    python3 tools/round_profile_report.py gpurun_out/prof_$tag $S/${R}_bench_$1_$2 $S/${R}_gemm_traffic_$1_$2.json \
+        "python3 bench.py --steps 10 --warmup 3 --cpu-baseline-samples 0 --no-roofline --no-fewshot --no-extra-train --no-t0 $extra" gpurun_out/prof_$tag/hbm_bytes.json > gpurun_out/report_$tag.log 2>&1
+    echo "$tag report rc=$?"; tail -3 gpurun_out/report_$tag.log
+    cp gpurun_out/prof_$tag/plain.json $S/plain_$1_$2.json 2>/dev/null
+    rm -rf gpurun_out/prof_$tag
+  done
+  bash tools/gpu_prof_fewshot.sh $R > $S/${R}_fewshot_stats.txt 2>&1; echo "fewshot rc=$?"
+  cp gpurun_out/prof_fewshot_$R/stats/*kernel_stats.csv $S/${R}_fewshot_kernel_stats_raw.csv 2>/dev/null
+  rm -rf gpurun_out/prof_fewshot_$R
+  bash tools/gpu_t0_prof.sh > $S/${R}_t0_fewshot_stats.txt 2>&1; echo "t0 rc=$?"
+  du -sh gpurun_out; ls -la $S
+  exit 0
+fi
 TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 6 --warmup 2 --cpu-baseline-samples 0 --no-roofline --no-fewshot --no-extra-train $@"
+ARGS="--steps 6 --warmup 2 --cpu-baseline-samples 0 --no-roofline --no-fewshot --no-extra-train --no-t0 $@"
 # 0. un-profiled: the byte model of the HBM-bound ops of one step (input of round_profile_report.py's _hbm.md)
-python3 $ROOT/bench.py --steps 3 --warmup 2 --cpu-baseline-samples 0 --no-fewshot --no-extra-train --hbm-bytes-out $OUT/hbm_bytes.json "$@" > $OUT/plain.json 2> $OUT/plain.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $ROOT/bench.py --steps 10 --warmup 3 --cpu-baseline-samples 0 --no-roofline --no-fewshot --no-extra-train "$@" > $OUT/stats.log 2>&1
+python3 $ROOT/bench.py --steps 3 --warmup 2 --cpu-baseline-samples 0 --no-fewshot --no-extra-train --no-t0 --hbm-bytes-out $OUT/hbm_bytes.json "$@" > $OUT/plain.json 2> $OUT/plain.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- python3 $ROOT/bench.py --steps 10 --warmup 3 --cpu-baseline-samples 0 --no-roofline --no-fewshot --no-extra-train --no-t0 "$@" > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o run -- python3 $ROOT/bench.py $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -o run -- python3 $ROOT/bench.py $ARGS > $OUT/write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_BUSY_CYCLES --output-format csv -d $OUT/mfma -o run -- python3 $ROOT/bench.py $ARGS > $OUT/mfma.log 2>&1
