@@ -44,6 +44,9 @@ SIGNATURES = {
     "eavqa_gemm_splitk": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i32, ptr],
     "eavqa_splitk_finish": [i32, i32, i32, ptr, i32, ptr, i32, ptr, i64, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr],
     "eavqa_layernorm_splitk": [i32, i32, i32, ptr, i64, ptr, i32, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, ptr],
+    "eavqa_gemm_fp8_splitk_plan": [i32, i32, i32],
+    "eavqa_gemm_fp8_splitk": [i32, i32, i32, ptr, i64, ptr, ptr, i64, f32, ptr, i32, ptr],
+    "eavqa_layernorm_splitk_fp8": [i32, i32, ptr, i64, ptr, i32, ptr, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, ptr],
     "eavqa_rmsnorm_splitk": [i32, i32, i32, ptr, i64, ptr, i32, ptr, i64, ptr, f32, ptr, i64, ptr],
     "eavqa_splitk_finish_gated": [i32, i32, i32, ptr, i32, i32, ptr, i64, ptr],
     "eavqa_attention_decode_splitk_rel": [i32, i32, i32, i32, i32, ptr, i32, i32, ptr, i64, ptr, i64, i64, ptr, i64, ptr, i64, f32, ptr, i64, i32, ptr],
@@ -75,6 +78,11 @@ class LMLayer(C.Structure):
                                           "w_fc2", "b_fc2", "k_cache", "v_cache")]
 
 
+class LMLayerScales(C.Structure):
+    """``eavqa_lm_layer_scales_t``."""
+    _fields_ = [(n, C.c_float) for n in ("s_qkv", "s_o", "s_fc1", "s_fc2")]
+
+
 class T5DecLayer(C.Structure):
     """``eavqa_t5_dec_layer_t``."""
     _fields_ = [(n, C.c_void_p) for n in ("ln_sa", "w_qkv", "w_o", "ln_ca", "w_q_ca", "w_o_ca", "ln_ff", "w_i", "w_o_ff", "k_cache", "v_cache",
@@ -95,6 +103,8 @@ SIGNATURES["eavqa_t5_decoder_step_workspace_bytes"] = [i32, i32, i32, i32, i32, 
 SIGNATURES["eavqa_t5_decoder_step"] = [i32, i32, C.POINTER(T5DecLayer), ptr, i32, i32, i32, i32, i32, i32, f32, i32, i32, i32, i32, ptr, ptr, ptr, i64,
                                        ptr, i64, i32, ptr, i64, ptr]
 SIGNATURES["eavqa_lm_block_workspace_bytes"] = [i32, i32, i32, i32]
+SIGNATURES["eavqa_lm_block_fp8_workspace_bytes"] = [i32, i32, i32]
+SIGNATURES["eavqa_lm_block_forward_fp8"] = [i32, C.POINTER(LMLayer), C.POINTER(LMLayerScales), i32, i32, i32, i32, f32, i32, i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr]
 SIGNATURES["eavqa_lm_block_forward"] = [i32, i32, C.POINTER(LMLayer), i32, i32, i32, i32, f32, i32, i32, i32, i32, ptr, ptr, i64, ptr, i64, ptr]
 
 # include/eavqa_test.h: the same entry points with an explicit kernel selector (tests and tools only)
@@ -106,7 +116,7 @@ SIGNATURES["eavqa_lm_block_forward_ex"] = SIGNATURES["eavqa_lm_block_forward"] +
 SIGNATURES["eavqa_gemm_decode_ex"] = SIGNATURES["eavqa_gemm_decode"] + [i32]
 SIGNATURES["eavqa_t5_decoder_step_ex"] = SIGNATURES["eavqa_t5_decoder_step"] + [i32]
 
-_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_lm_block_workspace_bytes": C.c_int64, "eavqa_t5_decoder_step_workspace_bytes": C.c_int64}
+_RESTYPES = {"eavqa_strerror": C.c_char_p, "eavqa_lm_block_workspace_bytes": C.c_int64, "eavqa_lm_block_fp8_workspace_bytes": C.c_int64, "eavqa_t5_decoder_step_workspace_bytes": C.c_int64}
 
 _lib = None
 

@@ -110,6 +110,94 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_splitk_kernel(const bf16_t*
     }
 }
 
+// The same kernel for a frozen LM held in e4m3 (BASELINE configs[4]): A = the activation rows quantised to e4m3 with one scale per row
+// (eavqa_quantize_rows_fp8 / the fp8 output of eavqa_layernorm_splitk), B = e4m3 weights with one scale per tensor.  A k-step is 64 values
+// = 64 bytes per row - the bf16 kernel's tile geometry in bytes: lane (x, g) holds bytes 16 g .. 16 g + 15 of its row for both operands
+// (the same permutation of the k-values on both sides) and feeds them to two v_mfma_f32_16x16x32_fp8_fp8; products of e4m3 values are
+// exact in fp32, so the partial sums differ from eavqa_gemm_fp8's accumulator by summation order only.  The row and tensor scales are
+// applied before the partial sums are written: every consumer of bf16 partial sums (LayerNorm pass, finish, decode attention) takes them
+// unchanged.  Half the weight bytes per step of the bf16 decode.
+template <int MF, int NF, int NW, int U>
+__global__ __launch_bounds__(64 * NW) void gemm_fp8_splitk_kernel(const unsigned char* __restrict__ A, int64_t lda, const float* __restrict__ a_scale,
+                                                                  const unsigned char* __restrict__ B, int64_t ldb, float b_scale,
+                                                                  float* __restrict__ P, int M, int N, int KS) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 16 * MF * 64;                      // bytes of one [16 MF rows][64 k] A tile
+    constexpr int COLS = 16 * NF * NW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * COLS + wave * 16 * NF, slice = blockIdx.y, k0 = slice * KS;
+    const int nsteps = KS >> 6;
+    const int x = lane & 15, g = lane >> 4;
+    const unsigned char* bp[NF];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) bp[j] = B + (int64_t)min(n0 + 16 * j + x, N - 1) * ldb + k0 + 16 * g;
+    uint4 bf[U][NF];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) bf[u][j] = *reinterpret_cast<const uint4*>(bp[j] + 64 * min(u, nsteps - 1));
+    const int total = nsteps * 64 * MF;
+    for (int base = wave * 64; base < total; base += 64 * NW) {
+        const int c = base + lane;
+        if (c < total) {
+            const int t = c / (64 * MF), within = c % (64 * MF);
+            const int row = within >> 2, pc = within & 3;
+            const unsigned char* src = A + (int64_t)min(row, M - 1) * lda + k0 + t * 64 + ((pc ^ ((-(row >> 2)) & 3)) << 4);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(smem + base * 16), 16, 0, 0);
+        }
+    }
+    f32x4 acc[MF][NF];
+#pragma unroll
+    for (int i = 0; i < MF; ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int a_off = fswz(x, g);
+    __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);
+    __syncthreads();
+    auto lo64 = [](const uint4& v) { return (long)(((unsigned long long)v.y << 32) | v.x); };
+    auto hi64 = [](const uint4& v) { return (long)(((unsigned long long)v.w << 32) | v.z); };
+    for (int s0 = 0; s0 < nsteps; s0 += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            uint4 w[NF];
+#pragma unroll
+            for (int j = 0; j < NF; ++j) w[j] = bf[u][j];
+            if (s0 + U + u < nsteps) {
+#pragma unroll
+                for (int j = 0; j < NF; ++j) bf[u][j] = *reinterpret_cast<const uint4*>(bp[j] + 64 * (s0 + U + u));
+            }
+            if (s0 + u < nsteps) {
+                const char* tile = smem + (s0 + u) * TILE;
+#pragma unroll
+                for (int i = 0; i < MF; ++i) {
+                    const uint4 af = *reinterpret_cast<const uint4*>(tile + a_off + i * 1024);
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(lo64(af), lo64(w[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(hi64(af), hi64(w[j]), acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NF; ++j) {
+        const int n = n0 + 16 * j + x;
+        if (n < N) {
+            float* out = P + (int64_t)slice * M * N + n;
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * i + 4 * g + r;
+                    if (m < M) out[(int64_t)m * N] = acc[i][j][r] * (a_scale[m] * b_scale);
+                }
+        }
+    }
+}
+
 struct FinishSeg { void* dst; int64_t ld; };
 
 // out[m, n] = act(sum_s P[s][m][n] + bias[n]) (+ residual[m, n]); 4 columns per thread
@@ -174,7 +262,8 @@ template <typename T, int NV>
 __global__ __launch_bounds__(LNS_NT) void ln_splitk_kernel(int rows, int cols, const float* __restrict__ x_in, int64_t ldx,
                                                            const float* __restrict__ P, int ks, const float* __restrict__ bias,
                                                            float* __restrict__ x_out, int64_t ldxo, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, T* __restrict__ y, int64_t ldy, int rms) {
+                                                           const float* __restrict__ beta, float eps, T* __restrict__ y, int64_t ldy, int rms,
+                                                           unsigned char* __restrict__ yq, int64_t ldq, float* __restrict__ yq_scale) {
     __shared__ float red[LNS_NT / 64];
     const int row = blockIdx.x, tid = threadIdx.x;
     const int nv = cols >> 2;
@@ -243,16 +332,41 @@ __global__ __launch_bounds__(LNS_NT) void ln_splitk_kernel(int rows, int cols, c
         }
     }
     const float rs = rsqrtf(block_sum8(q, red) / (float)cols + eps);
+    float4 o[NV];
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = tid + LNS_NT * i;
         if (c < nv) {
-            float4 o;
-            o.x = (v[i].x - mu) * rs * gm[i].x + bt[i].x;
-            o.y = (v[i].y - mu) * rs * gm[i].y + bt[i].y;
-            o.z = (v[i].z - mu) * rs * gm[i].z + bt[i].z;
-            o.w = (v[i].w - mu) * rs * gm[i].w + bt[i].w;
-            elem<T>::st4(y + (int64_t)row * ldy + 4 * c, o);
+            o[i].x = (v[i].x - mu) * rs * gm[i].x + bt[i].x;
+            o[i].y = (v[i].y - mu) * rs * gm[i].y + bt[i].y;
+            o[i].z = (v[i].z - mu) * rs * gm[i].z + bt[i].z;
+            o[i].w = (v[i].w - mu) * rs * gm[i].w + bt[i].w;
+            if (y) elem<T>::st4(y + (int64_t)row * ldy + 4 * c, o[i]);
+            if (yq) {          // what eavqa_quantize_rows_fp8 would see: the values rounded to the storage type first
+                o[i].x = (float)(T)o[i].x; o[i].y = (float)(T)o[i].y; o[i].z = (float)(T)o[i].z; o[i].w = (float)(T)o[i].w;
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o[i].x), fabsf(o[i].y)), fmaxf(fabsf(o[i].z), fabsf(o[i].w))));
+            }
+        }
+    }
+    if (yq) {
+        // the row-wise e4m3 quantisation of eavqa_quantize_rows_fp8, fused: scale = amax / 448 (1 for an all-zero row), same arithmetic
+        amax = wave_max(amax);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = amax;
+        __syncthreads();
+        amax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));
+        const float scale = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+        const float inv = 1.f / scale;
+        if (tid == 0) yq_scale[row] = scale;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = tid + LNS_NT * i;
+            if (c < nv) {
+                int pk = __builtin_amdgcn_cvt_pk_fp8_f32(o[i].x * inv, o[i].y * inv, 0, false);
+                pk = __builtin_amdgcn_cvt_pk_fp8_f32(o[i].z * inv, o[i].w * inv, pk, true);
+                *reinterpret_cast<int*>(yq + (int64_t)row * ldq + 4 * c) = pk;
+            }
         }
     }
 }
@@ -329,6 +443,50 @@ extern "C" int eavqa_gemm_splitk_ex(int dtype, int M, int N, int K, const void* 
     return gemm_splitk_impl(dtype, M, N, K, A, lda, B, ldb, partials, ks, stream, unroll);
 }
 
+// fp8 plan: the bf16 rules in bytes - a k-step is 64 values, the staged A slice KS x 16 MF bytes, slices of at least 512 values
+extern "C" int eavqa_gemm_fp8_splitk_plan(int M, int N, int K) {
+    if (M <= 0 || M > 64 || N <= 0 || K <= 0 || K % 64) return 0;
+    const int mf = splitk_mf(M), groups = (N + 127) / 128;
+    int best = 0, one_round = 0, fine = 0;
+    for (int ks = 1; ks <= 32; ++ks) {
+        if (K % (64 * ks)) continue;
+        const int KS = K / ks;
+        if (KS * mf * 16 > 64 * 1024) continue;
+        if (!best) best = ks;
+        if (groups * ks <= 256 && KS >= 512) one_round = ks;
+        if (KS >= 1024) fine = ks;
+    }
+    return one_round ? one_round : (fine > best ? fine : best);
+}
+
+extern "C" int eavqa_gemm_fp8_splitk(int M, int N, int K, const void* A, int64_t lda, const float* a_row_scale, const void* B, int64_t ldb,
+                                     float b_scale, float* partials, int ks, void* stream) {
+    if (!A || !B || !a_row_scale || !partials || M <= 0 || M > 64 || N <= 0 || K <= 0 || ks <= 0) return EAVQA_E_ARG;
+    if (K % (64 * ks) || lda < K || ldb < K) return EAVQA_E_SHAPE;
+    if (lda % 16 || ldb % 16 || !eavqa_aligned16(A) || !eavqa_aligned16(B)) return EAVQA_E_ALIGN;
+    const int mf = splitk_mf(M), KS = K / ks;
+    const int lds = KS * mf * 16;
+    if (lds > 150 * 1024) return EAVQA_E_SHAPE;
+    const int U = KS >= 1024 ? 16 : 8;
+    typedef void (*kernel_t)(const unsigned char*, int64_t, const float*, const unsigned char*, int64_t, float, float*, int, int, int);
+    static const kernel_t kernels[3][2] = {{gemm_fp8_splitk_kernel<1, 1, 8, 8>, gemm_fp8_splitk_kernel<1, 1, 8, 16>},
+                                           {gemm_fp8_splitk_kernel<2, 1, 8, 8>, gemm_fp8_splitk_kernel<2, 1, 8, 16>},
+                                           {gemm_fp8_splitk_kernel<4, 1, 8, 8>, gemm_fp8_splitk_kernel<4, 1, 8, 16>}};
+    static std::atomic<bool> configured[3][2];
+    const int im = mf == 1 ? 0 : (mf == 2 ? 1 : 2), iu = U == 16;
+    const kernel_t kernel = kernels[im][iu];
+    if (!configured[im][iu].load(std::memory_order_acquire)) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+            return EAVQA_E_LAUNCH;
+        configured[im][iu].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL(kernel, dim3((N + 127) / 128, ks), dim3(512), lds, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const unsigned char*>(A), lda, a_row_scale, reinterpret_cast<const unsigned char*>(B), ldb, b_scale, partials,
+                       M, N, KS);
+    EAVQA_LAUNCH_CHECK();
+    return EAVQA_OK;
+}
+
 extern "C" int eavqa_splitk_finish(int dtype, int M, int N, const float* partials, int ks, const float* bias, int act,
                                    const float* residual, int64_t ld_residual, int out_f32, int n_seg,
                                    void* out0, int64_t ld0, void* out1, int64_t ld1, void* out2, int64_t ld2, void* stream) {
@@ -370,9 +528,11 @@ extern "C" int eavqa_splitk_finish_gated(int dtype, int M, int F, const float* p
 
 static int norm_splitk_impl(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,
                             const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
-                            float eps, void* y, int64_t ldy, void* stream, int rms) {
+                            float eps, void* y, int64_t ldy, void* stream, int rms, void* yq = nullptr, int64_t ldq = 0,
+                            float* yq_scale = nullptr) {
     if (dtype != EAVQA_BF16 && dtype != EAVQA_F32) return EAVQA_E_DTYPE;
-    if (!x_in || !gamma || !beta || !y || rows <= 0 || cols <= 0 || ks < 0 || (ks > 0 && !partials)) return EAVQA_E_ARG;
+    if (!x_in || !gamma || !beta || (!y && !yq) || rows <= 0 || cols <= 0 || ks < 0 || (ks > 0 && !partials)) return EAVQA_E_ARG;
+    if (yq && (!yq_scale || ldq % 4)) return EAVQA_E_ARG;
     if (cols % 4 || cols > 64 * 4 * 16) return EAVQA_E_SHAPE;
     if (ldx % 4 || ldy % 4 || (x_out && ld_out % 4)) return EAVQA_E_ALIGN;
     const int nv = (cols / 4 + LNS_NT - 1) / LNS_NT;
@@ -380,7 +540,7 @@ static int norm_splitk_impl(int dtype, int rows, int cols, const float* x_in, in
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define EAVQA_LNS(T, NV)                                                                                                    \
     hipLaunchKernelGGL((ln_splitk_kernel<T, NV>), grid, block, 0, s, rows, cols, x_in, ldx, partials, ks, bias, x_out, ld_out, \
-                       gamma, beta, eps, reinterpret_cast<T*>(y), ldy, rms)
+                       gamma, beta, eps, reinterpret_cast<T*>(y), ldy, rms, reinterpret_cast<unsigned char*>(yq), ldq, yq_scale)
     if (dtype == EAVQA_BF16) {
         if (nv <= 1) EAVQA_LNS(bf16_t, 1); else if (nv <= 2) EAVQA_LNS(bf16_t, 2); else EAVQA_LNS(bf16_t, 4);
     } else {
@@ -396,6 +556,13 @@ extern "C" int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float
                                       float eps, void* y, int64_t ldy, void* stream) {
     if (!beta) return EAVQA_E_ARG;
     return norm_splitk_impl(dtype, rows, cols, x_in, ldx, partials, ks, bias, x_out, ld_out, gamma, beta, eps, y, ldy, stream, 0);
+}
+
+extern "C" int eavqa_layernorm_splitk_fp8(int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks, const float* bias,
+                                          float* x_out, int64_t ld_out, const float* gamma, const float* beta, float eps, void* yq, int64_t ldq,
+                                          float* row_scale, void* stream) {
+    if (!beta || !yq) return EAVQA_E_ARG;
+    return norm_splitk_impl(EAVQA_BF16, rows, cols, x_in, ldx, partials, ks, bias, x_out, ld_out, gamma, beta, eps, nullptr, 4, stream, 0, yq, ldq, row_scale);
 }
 
 extern "C" int eavqa_rmsnorm_splitk(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,

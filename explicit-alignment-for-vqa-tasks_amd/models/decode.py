@@ -4,7 +4,8 @@ Two drivers produce the same token ids:
   * ``use_cache=False`` - the reference's algorithm verbatim: every step re-runs the whole, growing
     sequence (clipcap.py:414-419);
   * ``use_cache=True``  - prefill once, keep per-layer K/V in HBM ``[B, S_max, E]`` and run one
-    token per step; a decode step is weight-streaming (HBM) bound.
+    token per step; a decode step is weight-streaming (HBM) bound.  An LM held in e4m3 streams half the bytes
+    (``eavqa_lm_block_forward_fp8``; every Linear = row-quantised activations x e4m3 weights, as in the re-forward loop).
 Token bookkeeping (argmax, pad for finished rows, eos flags) is one kernel per step
 (``eavqa_greedy_pick``); the host reads the ``unfinished`` flags back once per step only to
 honour the reference's early exit (clipcap.py:463).
@@ -32,16 +33,6 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
     last decode step."""
     dev = lm.device
     S_max = S0 + max_length
-    if use_cache and getattr(lm, "weight_format", "native") != "native":
-        # the cached driver (eavqa_lm_block_forward) streams bf16 / fp32 weights; an fp8 LM takes the reference's own algorithm
-        # (full re-forward per token, src/models/clipcap.py:414-419) through the fp8 GEMMs - same ids, more work
-        global _warned_fp8_cache
-        if not _warned_fp8_cache:
-            import warnings
-            warnings.warn("greedy_decode: the KV-cached driver has no fp8-weight route; generating with use_cache=False "
-                          "(full re-forward per token, the reference's own loop)", RuntimeWarning, stacklevel=2)
-            _warned_fp8_cache = True
-        use_cache = False
     tokens = torch.zeros((B, max_length), dtype=torch.int64, device=dev)
     raw = torch.empty(B, dtype=torch.int32, device=dev)
     unfinished = torch.ones(B, dtype=torch.int32, device=dev)
@@ -80,9 +71,6 @@ def greedy_decode(lm: FrozenCausalLM, prefix_rows: Tensor, src: Tensor, mask: Te
     return ids
 
 
-_warned_fp8_cache = False
-
-
 def _mark(marks: Optional[list], name: str) -> None:
     if marks is not None:
         ev = torch.cuda.Event(enable_timing=True)
@@ -91,25 +79,34 @@ def _mark(marks: Optional[list], name: str) -> None:
 
 
 class _KVCache:
-    """Per-layer K/V ``[B, S_max, E]`` plus the host-side layer table and scratch for ``eavqa_lm_block_forward``."""
+    """Per-layer K/V ``[B, S_max, E]`` plus the host-side layer table and scratch for ``eavqa_lm_block_forward`` - or, for an LM held in e4m3
+    (``weight_format="fp8"``), for ``eavqa_lm_block_forward_fp8``: the table then points at the weight BYTES and a second table carries the
+    per-tensor scales."""
 
     def __init__(self, lm: FrozenCausalLM, B: int, S_max: int, max_rows: int):
-        if getattr(lm, "weight_format", "native") != "native":
-            raise NotImplementedError("cached generation streams bf16 / fp32 weights (eavqa_lm_block_forward); an fp8 LM generates with "
-                                      "use_cache=False (the reference's own full re-forward, src/models/clipcap.py:414-419)")
         E, F = lm.cfg.n_embd, lm.cfg.ffn
+        self.fp8 = getattr(lm, "weight_format", "native") == "fp8"
         self.k = [torch.empty((B * S_max, E), device=lm.device, dtype=lm.dtype) for _ in lm.layers]
         self.v = [torch.empty((B * S_max, E), device=lm.device, dtype=lm.dtype) for _ in lm.layers]
         self.table = (_lib.LMLayer * len(lm.layers))()
+        self.scales = (_lib.LMLayerScales * len(lm.layers))() if self.fp8 else None
         for i, L in enumerate(lm.layers):
             t = self.table[i]
-            for name in ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2"):
+            for name in ("ln1_g", "ln1_b", "b_qkv", "b_o", "ln2_g", "ln2_b", "b_fc1", "b_fc2"):
                 setattr(t, name, getattr(L, name).data_ptr())
+            for name in ("w_qkv", "w_o", "w_fc1", "w_fc2"):
+                w = getattr(L, name)
+                setattr(t, name, (w.q if self.fp8 else w).data_ptr())
+                if self.fp8:
+                    setattr(self.scales[i], "s_" + name[2:], w.scale)
             t.k_cache, t.v_cache = self.k[i].data_ptr(), self.v[i].data_ptr()
         lib = _lib.load()
         # prefill (max_rows = B * S0 rows) and decode steps (B rows; their split-K partial sums) share one workspace
-        self.ws_bytes = max(int(lib.eavqa_lm_block_workspace_bytes(ops.dtype_id(lm.dtype), max_rows, E, F)),
-                            int(lib.eavqa_lm_block_workspace_bytes(ops.dtype_id(lm.dtype), B, E, F)))
+        if self.fp8:
+            self.ws_bytes = max(int(lib.eavqa_lm_block_fp8_workspace_bytes(max_rows, E, F)), int(lib.eavqa_lm_block_fp8_workspace_bytes(B, E, F)))
+        else:
+            self.ws_bytes = max(int(lib.eavqa_lm_block_workspace_bytes(ops.dtype_id(lm.dtype), max_rows, E, F)),
+                                int(lib.eavqa_lm_block_workspace_bytes(ops.dtype_id(lm.dtype), B, E, F)))
         self.ws = torch.empty(self.ws_bytes, device=lm.device, dtype=torch.uint8)
 
 
@@ -117,6 +114,10 @@ def _block(lm: FrozenCausalLM, cache: _KVCache, x: Tensor, mask: Tensor, B: int,
     """All decoder layers for ``Sq`` new positions per row starting at sequence index ``row0`` (one C call): K/V of the
     new positions are appended to the cache and attention runs against rows [0, row0+Sq).  ``x`` is updated in place."""
     c = lm.cfg
+    if cache.fp8:
+        _lib.call("eavqa_lm_block_forward_fp8", len(lm.layers), cache.table, cache.scales, c.n_embd, c.n_head, c.ffn, _lib.ACT[c.act], float(c.eps),
+                  B, Sq, row0, S_max, x.data_ptr(), mask.data_ptr(), mask.stride(0), cache.ws.data_ptr(), cache.ws_bytes, ops._stream())
+        return x
     args = (ops.dtype_id(lm.dtype), len(lm.layers), cache.table, c.n_embd, c.n_head, c.ffn, _lib.ACT[c.act], float(c.eps), B, Sq, row0, S_max,
             x.data_ptr(), mask.data_ptr(), mask.stride(0), cache.ws.data_ptr(), cache.ws_bytes, ops._stream())
     if ops.KernelSelect.decode_route:

@@ -426,6 +426,30 @@ def layernorm_splitk(x_in: Tensor, gamma: Tensor, beta: Tensor, eps: float, out_
     return y
 
 
+def gemm_fp8_splitk(a_q: Tensor, a_scale: Tensor, b_q: Tensor, b_scale: float, ks: Optional[int] = None, out: Optional[Tensor] = None) -> Tensor:
+    """fp32 partial sums [ks, M, N] (scales applied) of e4m3 rows ``a_q`` [M, K] x e4m3 weights ``b_q`` [N, K]^T (``eavqa_gemm_fp8_splitk``)."""
+    M, K = a_q.shape
+    N = b_q.shape[0]
+    if ks is None:
+        ks = int(_lib.load().eavqa_gemm_fp8_splitk_plan(M, N, K))
+        if ks <= 0:
+            raise _lib.EavqaError(f"eavqa_gemm_fp8_splitk: unsupported shape M={M} N={N} K={K}")
+    part = out if out is not None else torch.empty((ks, M, N), device=a_q.device, dtype=torch.float32)
+    call("eavqa_gemm_fp8_splitk", M, N, K, _p(a_q), _ld(a_q), _p(a_scale), _p(b_q), _ld(b_q), float(b_scale), _p(part), ks, _stream())
+    return part
+
+
+def layernorm_splitk_fp8(x_in: Tensor, gamma: Tensor, beta: Tensor, eps: float, part: Optional[Tensor] = None, bias: Optional[Tensor] = None,
+                         x_out: Optional[Tensor] = None):
+    """``layernorm_splitk`` whose output feeds an fp8 GEMM: (e4m3 bytes uint8 [rows, cols], float32 row scales [rows])."""
+    rows, cols = x_in.shape
+    yq = torch.empty((rows, cols), device=x_in.device, dtype=torch.uint8)
+    sc = torch.empty(rows, device=x_in.device, dtype=torch.float32)
+    call("eavqa_layernorm_splitk_fp8", rows, cols, _p(x_in), _ld(x_in), _p(part), 0 if part is None else part.shape[0], _p(bias), _p(x_out),
+         _ld(x_out) if x_out is not None else 0, _p(gamma), _p(beta), float(eps), _p(yq), _ld(yq), _p(sc), _stream())
+    return yq, sc
+
+
 def rmsnorm_splitk(x_in: Tensor, gamma: Tensor, eps: float, out_dtype, part: Optional[Tensor] = None, x_out: Optional[Tensor] = None,
                    out: Optional[Tensor] = None) -> Tensor:
     """x = x_in + sum(part) (-> ``x_out``); returns T5LayerNorm(x) in ``out_dtype`` (``eavqa_rmsnorm_splitk``)."""

@@ -293,6 +293,17 @@ int eavqa_lm_block_forward(int dtype, int n_layer, const eavqa_lm_layer_t* layer
                            int B, int Sq, int row0, int S_max, float* x, const int32_t* key_mask, int64_t ld_mask,
                            void* workspace, int64_t workspace_bytes, void* stream);
 
+/* eavqa_lm_block_forward for an LM whose Linear weights are e4m3 bytes with one scale per tensor (BASELINE configs[4]; models/lm.py
+ * Fp8Weight): `layers[l].w_*` point at the bytes ([out, in], k contiguous), `scales[l]` holds the four tensor scales; activations, KV
+ * cache and biases as in the bf16 call.  Prefill quantises every GEMM's rows and multiplies on the fp8 matrix cores (eavqa_quantize_rows_fp8
+ * + eavqa_gemm_fp8: the arithmetic of the re-forward loop); a decode step (Sq = 1, <= 64 rows) streams the e4m3 weights once through
+ * eavqa_gemm_fp8_splitk.  E and F multiples of 128.  workspace >= eavqa_lm_block_fp8_workspace_bytes(B * Sq, E, F). */
+typedef struct { float s_qkv, s_o, s_fc1, s_fc2; } eavqa_lm_layer_scales_t;
+int64_t eavqa_lm_block_fp8_workspace_bytes(int rows, int E, int F);
+int eavqa_lm_block_forward_fp8(int n_layer, const eavqa_lm_layer_t* layers, const eavqa_lm_layer_scales_t* scales, int E, int H, int F, int act,
+                               float eps, int B, int Sq, int row0, int S_max, float* x, const int32_t* key_mask, int64_t ld_mask,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* One cached greedy step through all `n_layer` decoder layers of a frozen T5 (HF:models/t5/modeling_t5.py T5Block x n: self-attention with
  * the relative-position bias, cross-attention over the encoder output, (gated) feed-forward; RMSNorm, no biases, unscaled scores), for the
  * ONE new decoder position t - 1 of every sample: q / k / v of the new position, K / V appended to the per-layer cache [B, t_max, inner] at
@@ -333,6 +344,21 @@ int eavqa_splitk_finish(int dtype, int M, int N, const float* partials, int ks, 
 int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks,
                            const float* bias, float* x_out, int64_t ld_out, const float* gamma, const float* beta,
                            float eps, void* y, int64_t ldy, void* stream);
+
+/* The decode step of an LM held in e4m3 (BASELINE configs[4]; the forward it must agree with is eavqa_quantize_rows_fp8 + eavqa_gemm_fp8,
+ * HF:models/opt/modeling_opt.py:137-181,228-248 for one new token):
+ * eavqa_gemm_fp8_splitk: partials[s][m][n] = a_row_scale[m] * b_scale * sum_{k in slice s} A[m,k] B[n,k], A [M,K] and B [N,K] e4m3 bytes
+ *   (K % (64 ks) == 0, lda / ldb % 16 == 0): fp32 partial sums with the scales already applied, so eavqa_splitk_finish,
+ *   eavqa_layernorm_splitk and eavqa_attention_decode_splitk consume them as they consume the bf16 kernel's; half the weight bytes per
+ *   step.  eavqa_gemm_fp8_splitk_plan: recommended ks (0 = unsupported shape).
+ * eavqa_layernorm_splitk_fp8: eavqa_layernorm_splitk whose output is the NEXT fp8 GEMM's operand: LayerNorm(x) rounded to bfloat16, then
+ *   quantised row-wise exactly as eavqa_quantize_rows_fp8 does (yq e4m3 bytes [rows, ldq], row_scale float32 [rows]). */
+int eavqa_gemm_fp8_splitk_plan(int M, int N, int K);
+int eavqa_gemm_fp8_splitk(int M, int N, int K, const void* A, int64_t lda, const float* a_row_scale, const void* B, int64_t ldb,
+                          float b_scale, float* partials, int ks, void* stream);
+int eavqa_layernorm_splitk_fp8(int rows, int cols, const float* x_in, int64_t ldx, const float* partials, int ks, const float* bias,
+                               float* x_out, int64_t ld_out, const float* gamma, const float* beta, float eps, void* yq, int64_t ldq,
+                               float* row_scale, void* stream);
 
 /* The same three consumers for a T5 decoder step (HF:models/t5/modeling_t5.py T5Block; the reference reaches it through HF generate,
  * src/models/vct0.py:458-464):

@@ -276,25 +276,72 @@ def test_fp8_and_bf16_lm_train_the_mapper_alike(arch):
     assert (b[0] - b[-1]).item() >= 0.95 * drop and gap <= 0.05 * drop, (curves, gap, drop)
 
 
-def test_fp8_lm_generate_defaults_fall_back_to_the_uncached_loop():
-    """``generate()`` defaults to use_cache=True; the cached driver has no fp8 route, so an fp8 LM must take the reference's full
-    re-forward loop by itself and return the ids of an explicit use_cache=False call."""
-    import warnings
+@pytest.mark.parametrize("M,N,K,ks", [(32, 384, 256, 1), (32, 12288, 4096, 2), (5, 200, 1024, 4), (64, 2048, 512, 2), (17, 640, 2048, None)])
+def test_gemm_fp8_splitk_partial_sums(M, N, K, ks):
+    """eavqa_gemm_fp8_splitk: sum_s partials[s] == a_row_scale[m] * b_scale * (A_q B_q^T) - the e4m3 products are exact in fp32, so against a
+    float64 product of the SAME bytes only the summation order differs; and against eavqa_gemm_fp8 (the kernel the re-forward loop uses)."""
+    from eavqa_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    w = torch.randn(N, K, generator=g) * 0.05
+    aq, asc = ops.quantize_rows_fp8(a)
+    wmax = w.abs().max().item()
+    wq = (w / (wmax / 448.0)).to(torch.float8_e4m3fn).view(torch.uint8).contiguous().to(DEV)
+    bsc = wmax / 448.0
+    part = ops.gemm_fp8_splitk(aq, asc, wq, bsc, ks=ks)
+    got = part.double().sum(0).cpu()
+    ref = (aq.cpu().view(torch.float8_e4m3fn).double() @ wq.cpu().view(torch.float8_e4m3fn).double().T) * asc.cpu().double()[:, None] * bsc
+    assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item()) * math.sqrt(K / 64)
+    full = ops.gemm_fp8(aq, asc, wq, bsc, out_f32=True) if K % 128 == 0 else None
+    if full is not None:
+        assert (got - full.double().cpu()).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item()) * math.sqrt(K / 64)
+
+
+@pytest.mark.parametrize("rows,cols,ks", [(32, 4096, 8), (5, 256, 0), (64, 2560, 3), (1, 128, 1)])
+def test_layernorm_splitk_fp8_is_layernorm_then_row_quantiser(rows, cols, ks):
+    """eavqa_layernorm_splitk_fp8 == eavqa_layernorm_splitk (bf16 out) followed by eavqa_quantize_rows_fp8, byte for byte, and the same x_out."""
+    from eavqa_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x_in = (torch.randn(rows, cols, generator=g) + 0.3).to(DEV)
+    part = (torch.randn(max(ks, 1), rows, cols, generator=g) * 0.5).to(DEV) if ks else None
+    bias = torch.randn(cols, generator=g).to(DEV) if ks else None
+    gamma, beta = (1 + 0.2 * torch.randn(cols, generator=g)).to(DEV), (0.1 * torch.randn(cols, generator=g)).to(DEV)
+    x1, x2 = torch.empty_like(x_in), torch.empty_like(x_in)
+    y = ops.layernorm_splitk(x_in, gamma, beta, 1e-5, torch.bfloat16, part=part, bias=bias, x_out=x1)
+    q_ref, s_ref = ops.quantize_rows_fp8(y)
+    q, sc = ops.layernorm_splitk_fp8(x_in, gamma, beta, 1e-5, part=part, bias=bias, x_out=x2)
+    torch.cuda.synchronize()
+    assert torch.equal(x1, x2) and torch.equal(sc, s_ref) and torch.equal(q, q_ref)
+
+
+@pytest.mark.parametrize("arch", ["opt", "gpt2"])
+def test_fp8_lm_cached_generation_returns_the_ids_of_the_reforward_loop(arch):
+    """``generate()`` (use_cache=True by default) on an LM held in e4m3: prefill + cached decode steps through ``eavqa_lm_block_forward_fp8``
+    (e4m3 weights streamed once per step, rows quantised exactly as the re-forward path quantises them) returns the ids of
+    ``use_cache=False`` - the reference's own loop (src/models/clipcap.py:414-419) through the fp8 GEMMs."""
     from eavqa_amd.models.clipcap import ClipCaptionPrefix
     from eavqa_amd.models.lm import FrozenCausalLM, LMConfig, random_init_state_dict
-    cfg = LMConfig("opt", 2, 4, 256, 512, 640, 64, 1e-5, "relu", 2, 1)
-    lm = FrozenCausalLM(cfg, random_init_state_dict(cfg, 3, "cpu"), torch.bfloat16, DEV, weight_format="fp8")
+    cfg = (LMConfig("opt", 3, 4, 256, 512, 640, 64, 1e-5, "relu", 2, 1) if arch == "opt" else LMConfig("gpt2", 3, 4, 256, 512, 640, 64, 1e-5, "gelu_new", 639, None))
+    sd = random_init_state_dict(cfg, 3, "cpu")
+    for k in sorted(sd):
+        if sd[k].dim() == 2:
+            sd[k] = sd[k] * 3.0                                        # logits of a useful size: top-2 gaps far above the rounding noise
+    lm = FrozenCausalLM(cfg, sd, torch.bfloat16, DEV, weight_format="fp8")
     torch.manual_seed(1)
     model = ClipCaptionPrefix(prefix_length=4, prefix_size=32, mapping_type="mlp", lm=lm, dtype=torch.bfloat16, device=DEV).eval()
     g = torch.Generator().manual_seed(4)
-    ids = torch.randint(3, 600, (3, 9), generator=g)
-    mask = torch.ones(3, 9, dtype=torch.long)
-    prefix = torch.randn(3, 32, generator=g)
+    B, T = 5, 9
+    ids = torch.randint(3, 600, (B, T), generator=g)
+    mask = torch.ones(B, T, dtype=torch.long)
+    mask[1, 6:] = 0
+    mask[3, 4:] = 0
+    prefix = torch.randn(B, 32, generator=g)
+    import warnings
     with warnings.catch_warnings():
-        warnings.simplefilter("ignore", RuntimeWarning)
-        a = model.generate(question_tokens=ids, prefix=prefix, question_mask=mask, max_length=5, pad_token_id=1, eos_token_id=None)
-    b = model.generate(question_tokens=ids, prefix=prefix, question_mask=mask, max_length=5, pad_token_id=1, eos_token_id=None, use_cache=False)
-    assert a == b and len(a) == 3 and len(a[0]) == 5
+        warnings.simplefilter("error")                                # no fallback warning any more
+        a = model.generate(question_tokens=ids, prefix=prefix, question_mask=mask, max_length=6, pad_token_id=1, eos_token_id=None)
+    b = model.generate(question_tokens=ids, prefix=prefix, question_mask=mask, max_length=6, pad_token_id=1, eos_token_id=None, use_cache=False)
+    assert a == b and len(a) == B and len(a[0]) == 6
 
 
 def test_fp8_lm_rejects_unsupported_uses():
