@@ -111,39 +111,45 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_splitk_kernel(const bf16_t*
 }
 
 // The same kernel for a frozen LM held in e4m3 (BASELINE configs[4]): A = the activation rows quantised to e4m3 with one scale per row
-// (eavqa_quantize_rows_fp8 / the fp8 output of eavqa_layernorm_splitk), B = e4m3 weights with one scale per tensor.  A k-step is 64 values
-// = 64 bytes per row - the bf16 kernel's tile geometry in bytes: lane (x, g) holds bytes 16 g .. 16 g + 15 of its row for both operands
-// (the same permutation of the k-values on both sides) and feeds them to two v_mfma_f32_16x16x32_fp8_fp8; products of e4m3 values are
-// exact in fp32, so the partial sums differ from eavqa_gemm_fp8's accumulator by summation order only.  The row and tensor scales are
-// applied before the partial sums are written: every consumer of bf16 partial sums (LayerNorm pass, finish, decode attention) takes them
-// unchanged.  Half the weight bytes per step of the bf16 decode.
+// (eavqa_quantize_rows_fp8 / the fp8 output of eavqa_layernorm_splitk), B = e4m3 weights with one scale per tensor.  A k-step is 128 values
+// = one whole 128-byte line per row and ONE v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales - the instruction eavqa_gemm_fp8 uses,
+// so the partial sums differ from its accumulator by fp32 summation order only (the plain v_mfma_f32_16x16x32_fp8_fp8 adds its products with
+// fewer guard bits: 2e-5 relative against float64 - enough, through the e4m3 rounding of every following activation, to move logits by
+// percents between the cached and the re-forward generation).  Lane (x, g) holds the 16-byte chunks g and g + 4 of its row's step for both
+// operands (gemm_fp8.hip's fragment layout).  The row and tensor scales are applied before the partial sums are written: every consumer of
+// bf16 partial sums (LayerNorm pass, finish, decode attention) takes them unchanged.  Half the weight bytes per step of the bf16 decode.
+typedef __attribute__((ext_vector_type(8))) int dec_i32x8;
 template <int MF, int NF, int NW, int U>
 __global__ __launch_bounds__(64 * NW) void gemm_fp8_splitk_kernel(const unsigned char* __restrict__ A, int64_t lda, const float* __restrict__ a_scale,
                                                                   const unsigned char* __restrict__ B, int64_t ldb, float b_scale,
                                                                   float* __restrict__ P, int M, int N, int KS) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE = 16 * MF * 64;                      // bytes of one [16 MF rows][64 k] A tile
+    constexpr int TILE = 16 * MF * 128;                     // bytes of one [16 MF rows][128 k] A tile
     constexpr int COLS = 16 * NF * NW;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n0 = blockIdx.x * COLS + wave * 16 * NF, slice = blockIdx.y, k0 = slice * KS;
-    const int nsteps = KS >> 6;
+    const int nsteps = KS >> 7;
     const int x = lane & 15, g = lane >> 4;
     const unsigned char* bp[NF];
 #pragma unroll
     for (int j = 0; j < NF; ++j) bp[j] = B + (int64_t)min(n0 + 16 * j + x, N - 1) * ldb + k0 + 16 * g;
-    uint4 bf[U][NF];
+    uint4 blo[U][NF], bhi[U][NF];
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int j = 0; j < NF; ++j) bf[u][j] = *reinterpret_cast<const uint4*>(bp[j] + 64 * min(u, nsteps - 1));
-    const int total = nsteps * 64 * MF;
+        for (int j = 0; j < NF; ++j) {
+            blo[u][j] = *reinterpret_cast<const uint4*>(bp[j] + 128 * min(u, nsteps - 1));
+            bhi[u][j] = *reinterpret_cast<const uint4*>(bp[j] + 128 * min(u, nsteps - 1) + 64);
+        }
+    // A slice: chunk c -> tile c / (128 MF), row (c % (128 MF)) >> 3, physical slot c & 7 holds logical chunk slot ^ (row & 7)
+    const int total = nsteps * 128 * MF;
     for (int base = wave * 64; base < total; base += 64 * NW) {
         const int c = base + lane;
         if (c < total) {
-            const int t = c / (64 * MF), within = c % (64 * MF);
-            const int row = within >> 2, pc = within & 3;
-            const unsigned char* src = A + (int64_t)min(row, M - 1) * lda + k0 + t * 64 + ((pc ^ ((-(row >> 2)) & 3)) << 4);
+            const int t = c / (128 * MF), within = c % (128 * MF);
+            const int row = within >> 3, pc = within & 7;
+            const unsigned char* src = A + (int64_t)min(row, M - 1) * lda + k0 + t * 128 + ((pc ^ (row & 7)) << 4);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(smem + base * 16), 16, 0, 0);
         }
@@ -153,31 +159,34 @@ __global__ __launch_bounds__(64 * NW) void gemm_fp8_splitk_kernel(const unsigned
     for (int i = 0; i < MF; ++i)
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int a_off = fswz(x, g);
+    const int a_off = x * 128 + ((g ^ (x & 7)) << 4);       // chunk g; chunk g + 4 sits at a_off ^ 64
     __builtin_amdgcn_s_waitcnt(0x0070 | 0x0F00);
     __syncthreads();
-    auto lo64 = [](const uint4& v) { return (long)(((unsigned long long)v.y << 32) | v.x); };
-    auto hi64 = [](const uint4& v) { return (long)(((unsigned long long)v.w << 32) | v.z); };
+    auto frag = [](const uint4& lo, const uint4& hi) {
+        return (dec_i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+    };
     for (int s0 = 0; s0 < nsteps; s0 += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            uint4 w[NF];
+            dec_i32x8 w[NF];
 #pragma unroll
-            for (int j = 0; j < NF; ++j) w[j] = bf[u][j];
+            for (int j = 0; j < NF; ++j) w[j] = frag(blo[u][j], bhi[u][j]);
             if (s0 + U + u < nsteps) {
 #pragma unroll
-                for (int j = 0; j < NF; ++j) bf[u][j] = *reinterpret_cast<const uint4*>(bp[j] + 64 * (s0 + U + u));
+                for (int j = 0; j < NF; ++j) {
+                    blo[u][j] = *reinterpret_cast<const uint4*>(bp[j] + 128 * (s0 + U + u));
+                    bhi[u][j] = *reinterpret_cast<const uint4*>(bp[j] + 128 * (s0 + U + u) + 64);
+                }
             }
             if (s0 + u < nsteps) {
                 const char* tile = smem + (s0 + u) * TILE;
 #pragma unroll
                 for (int i = 0; i < MF; ++i) {
-                    const uint4 af = *reinterpret_cast<const uint4*>(tile + a_off + i * 1024);
+                    const dec_i32x8 af = frag(*reinterpret_cast<const uint4*>(tile + a_off + i * 2048),
+                                              *reinterpret_cast<const uint4*>(tile + (a_off ^ 64) + i * 2048));
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(lo64(af), lo64(w[j]), acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(hi64(af), hi64(w[j]), acc[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < NF; ++j)      // cbsz = blgp = 0: both operands e4m3; block scales 2^0 (E8M0 byte 127)
+                        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(af, w[j], acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
                 }
             }
         }
@@ -443,13 +452,13 @@ extern "C" int eavqa_gemm_splitk_ex(int dtype, int M, int N, int K, const void* 
     return gemm_splitk_impl(dtype, M, N, K, A, lda, B, ldb, partials, ks, stream, unroll);
 }
 
-// fp8 plan: the bf16 rules in bytes - a k-step is 64 values, the staged A slice KS x 16 MF bytes, slices of at least 512 values
+// fp8 plan: the bf16 rules in bytes - a k-step is 128 values, the staged A slice KS x 16 MF bytes, slices of at least 512 values
 extern "C" int eavqa_gemm_fp8_splitk_plan(int M, int N, int K) {
-    if (M <= 0 || M > 64 || N <= 0 || K <= 0 || K % 64) return 0;
+    if (M <= 0 || M > 64 || N <= 0 || K <= 0 || K % 128) return 0;
     const int mf = splitk_mf(M), groups = (N + 127) / 128;
     int best = 0, one_round = 0, fine = 0;
     for (int ks = 1; ks <= 32; ++ks) {
-        if (K % (64 * ks)) continue;
+        if (K % (128 * ks)) continue;
         const int KS = K / ks;
         if (KS * mf * 16 > 64 * 1024) continue;
         if (!best) best = ks;
@@ -462,18 +471,18 @@ extern "C" int eavqa_gemm_fp8_splitk_plan(int M, int N, int K) {
 extern "C" int eavqa_gemm_fp8_splitk(int M, int N, int K, const void* A, int64_t lda, const float* a_row_scale, const void* B, int64_t ldb,
                                      float b_scale, float* partials, int ks, void* stream) {
     if (!A || !B || !a_row_scale || !partials || M <= 0 || M > 64 || N <= 0 || K <= 0 || ks <= 0) return EAVQA_E_ARG;
-    if (K % (64 * ks) || lda < K || ldb < K) return EAVQA_E_SHAPE;
+    if (K % (128 * ks) || lda < K || ldb < K) return EAVQA_E_SHAPE;
     if (lda % 16 || ldb % 16 || !eavqa_aligned16(A) || !eavqa_aligned16(B)) return EAVQA_E_ALIGN;
     const int mf = splitk_mf(M), KS = K / ks;
     const int lds = KS * mf * 16;
     if (lds > 150 * 1024) return EAVQA_E_SHAPE;
-    const int U = KS >= 1024 ? 16 : 8;
+    const int U = KS >= 1024 ? 8 : 4;                       // 128-byte steps: 8 of them = the 16 loads per lane of the bf16 kernel's deep window
     typedef void (*kernel_t)(const unsigned char*, int64_t, const float*, const unsigned char*, int64_t, float, float*, int, int, int);
-    static const kernel_t kernels[3][2] = {{gemm_fp8_splitk_kernel<1, 1, 8, 8>, gemm_fp8_splitk_kernel<1, 1, 8, 16>},
-                                           {gemm_fp8_splitk_kernel<2, 1, 8, 8>, gemm_fp8_splitk_kernel<2, 1, 8, 16>},
-                                           {gemm_fp8_splitk_kernel<4, 1, 8, 8>, gemm_fp8_splitk_kernel<4, 1, 8, 16>}};
+    static const kernel_t kernels[3][2] = {{gemm_fp8_splitk_kernel<1, 1, 8, 4>, gemm_fp8_splitk_kernel<1, 1, 8, 8>},
+                                           {gemm_fp8_splitk_kernel<2, 1, 8, 4>, gemm_fp8_splitk_kernel<2, 1, 8, 8>},
+                                           {gemm_fp8_splitk_kernel<4, 1, 8, 4>, gemm_fp8_splitk_kernel<4, 1, 8, 8>}};
     static std::atomic<bool> configured[3][2];
-    const int im = mf == 1 ? 0 : (mf == 2 ? 1 : 2), iu = U == 16;
+    const int im = mf == 1 ? 0 : (mf == 2 ? 1 : 2), iu = U == 8;
     const kernel_t kernel = kernels[im][iu];
     if (!configured[im][iu].load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)

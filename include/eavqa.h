@@ -348,7 +348,7 @@ int eavqa_layernorm_splitk(int dtype, int rows, int cols, const float* x_in, int
 /* The decode step of an LM held in e4m3 (BASELINE configs[4]; the forward it must agree with is eavqa_quantize_rows_fp8 + eavqa_gemm_fp8,
  * HF:models/opt/modeling_opt.py:137-181,228-248 for one new token):
  * eavqa_gemm_fp8_splitk: partials[s][m][n] = a_row_scale[m] * b_scale * sum_{k in slice s} A[m,k] B[n,k], A [M,K] and B [N,K] e4m3 bytes
- *   (K % (64 ks) == 0, lda / ldb % 16 == 0): fp32 partial sums with the scales already applied, so eavqa_splitk_finish,
+ *   (K % (128 ks) == 0, lda / ldb % 16 == 0; the block-scaled 16x16x128 MFMA of eavqa_gemm_fp8 with unit block scales): fp32 partial sums with the scales already applied, so eavqa_splitk_finish,
  *   eavqa_layernorm_splitk and eavqa_attention_decode_splitk consume them as they consume the bf16 kernel's; half the weight bytes per
  *   step.  eavqa_gemm_fp8_splitk_plan: recommended ks (0 = unsupported shape).
  * eavqa_layernorm_splitk_fp8: eavqa_layernorm_splitk whose output is the NEXT fp8 GEMM's operand: LayerNorm(x) rounded to bfloat16, then
