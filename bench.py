@@ -104,9 +104,13 @@ class Stepper:
     Every step performs one forward/backward and one optimiser update, and one encode - except the very first step of a run,
     which also encodes its own batch to fill the pipeline (untimed: it falls into the warm-up)."""
 
-    def __init__(self, vit, model, opt, batch, pad, sync, overlap_vit=True):
+    def __init__(self, vit, model, opt, batch, pad, sync, overlap_vit=True, pipelined_update=True):
         self.vit, self.model, self.opt, self.batch, self.pad, self.sync = vit, model, opt, batch, pad, sync
         self.pending_update = False
+        # AdamW chunk by chunk on its own stream, the mapper's forward waiting layer by layer (FusedAdamW.step(chunks=...)): the update is
+        # HBM-bound, the mapper's GEMMs are not - the first layers run while the last ones are still being updated
+        mapper = getattr(model, "clip_project", None)
+        self.chunks = mapper.update_chunks() if (pipelined_update and hasattr(mapper, "update_chunks")) else None
         self.side = torch.cuda.Stream() if overlap_vit else None
         self.next_emb = None
         self.next_ready = None
@@ -115,7 +119,7 @@ class Stepper:
         if self.pending_update:
             self.sync.finish()
             if self.sync is not self.opt:            # the sharded optimiser has already updated its shard behind the reduce-scatter
-                self.opt.step(grad_scale=self.sync.grad_scale)
+                self.opt.step(grad_scale=self.sync.grad_scale, chunks=self.chunks)
             self.opt.zero_grad()
             self.pending_update = False
 
@@ -147,6 +151,9 @@ class Stepper:
         self._apply_update()                                     # all-reduce wait + AdamW of the previous step
         out = self.model(question_tokens=b["input_ids"], prefix=emb, question_mask=b["attention_mask"], labels=b["labels"],
                          pad_token_id=self.pad, question_lengths=b["question_lengths"], label_count=b["label_count"])
+        arm = getattr(self.sync, "arm", None)
+        if arm is not None:
+            arm()                                    # sharded exchange: reduce-scatter per bucket as the mapper's backward completes it
         out.loss.backward()
         self.sync.start()
         self.pending_update = True
@@ -376,7 +383,7 @@ def t0_cc_train_leg(dtype_name, steps, warmup, device, args):
     batch = {k: v.to(device) for k, v in batch.items()}
     batch["question_lengths"], batch["label_count"] = None, None
     sync = GradSync(vct0.clip_project.flat.grad, 1, exchange=True)
-    stepper = Stepper(vit, model, opt, batch, c.pad_token_id, sync, overlap_vit=not args.no_overlap)
+    stepper = Stepper(vit, model, opt, batch, c.pad_token_id, sync, overlap_vit=not args.no_overlap, pipelined_update=not args.no_pipelined_update)
     for _ in range(warmup):
         stepper.step()
     stepper.flush()
@@ -496,11 +503,12 @@ def train_leg(workload, dtype_name, steps, warmup, rank, world, device, args, lo
     if factors:
         model.clip_project.dp_factor_exchange = True
     if exchange == "sharded":
-        opt = ShardedAdamW(flat, lr=1e-4)            # exchange + update in one object (start / finish)
+        # exchange + update in one object (arm / start / finish)
+        opt = ShardedAdamW(flat, lr=1e-4, grad_transport=torch.bfloat16 if args.grad_transport == "bf16" else None)
         sync = opt
     else:
         sync = GradSync(flat.grad, world, exchange=not factors)
-    stepper = Stepper(vit, model, opt, batch, pad, sync, overlap_vit=not args.no_overlap)
+    stepper = Stepper(vit, model, opt, batch, pad, sync, overlap_vit=not args.no_overlap, pipelined_update=not args.no_pipelined_update)
 
     def barrier():
         torch.cuda.synchronize()
@@ -550,6 +558,11 @@ def train_leg(workload, dtype_name, steps, warmup, rank, world, device, args, lo
                     # MODELLED, never measured on a multi-GPU box: what the chooser compared
                     "dp_exchange_model_ms_unmeasured": {k: round(v * 1e3, 2) for k, v in dp_exchange_costs(
                         flat.numel, flat.numel if has_factors else 0, w["batch"], world).items()},
+                    # the same model if RCCL's reduce-scatter / all-gather spread over all seven xGMI links of a GPU: the first multi-GPU run's
+                    # dp_exchange_ms_per_step below says which of the two the hardware is closer to
+                    "dp_exchange_model_ms_7_links_unmeasured": {k: round(v * 1e3, 2) for k, v in dp_exchange_costs(
+                        flat.numel, flat.numel if has_factors else 0, w["batch"], world, links=7).items()},
+                    "grad_transport": args.grad_transport,
                     "dp_exchange_ms_per_step": stepper.exchange_ms()}
     line = {
         "metric": "mapper_train_samples_per_sec", "value": round(value, 2), "unit": "samples/s", "n_gpus": world,
@@ -590,6 +603,10 @@ def main():
     ap.add_argument("--no-fewshot", action="store_true", help="skip the few-shot generate leg (metric M2, reported under 'extra')")
     ap.add_argument("--no-extra-train", action="store_true",
                     help="skip the short cfg3 (bf16) and cfg5 (fp8) training legs that the default cfg2 run reports under 'extra'")
+    ap.add_argument("--grad-transport", choices=["f32", "bf16"], default="f32",
+                    help="N > 1, sharded exchange: dtype of the gradient on the wire (bf16: 4 instead of 6 B / parameter, the sum rounded per hop)")
+    ap.add_argument("--no-pipelined-update", action="store_true",
+                    help="one AdamW launch on the main stream in front of the mapper's forward (default: chunk by chunk on its own stream, the forward waits per layer)")
     ap.add_argument("--no-t0", action="store_true",
                     help="skip the two T0_3B legs (the reference's headline model: few-shot generate and CC mapper training) reported under 'extra'")
     ap.add_argument("--hbm-bytes-out", default=None,
@@ -764,7 +781,7 @@ def step_roofline(vit, model, opt, batch, pad, sync, ops, workload="cfg2", dtype
         fn, model_bytes = real[name], models[name][1]
         return lambda *a, **k: bracket("hbm:" + name, 0.0, float(model_bytes(*a, **k)), lambda: fn(*a, **k))
 
-    serial = Stepper(vit, model, opt, batch, pad, sync, overlap_vit=False)
+    serial = Stepper(vit, model, opt, batch, pad, sync, overlap_vit=False, pipelined_update=False)      # one stream: clean brackets
     enc = vit.encode_image
 
     def tagged_encode(px):

@@ -65,6 +65,34 @@ class FlatParams:
         self.shadow = self.master if compute_dtype == torch.float32 else torch.zeros(off, device=device, dtype=compute_dtype)
         self._shadow_version = -1
         self.grad_live = False   # False: the next backward overwrites ``grad`` instead of accumulating
+        # pipelined optimiser (FusedAdamW.step(chunks=...)): (lo, hi, event) of parameter ranges whose update is still running on the
+        # optimiser's stream - the mapper's forward waits for the ranges it is about to read (``wait_ready``)
+        self._ready: List[Tuple[int, int, object]] = []
+        # data parallel (ShardedAdamW.arm): callables (lo, hi) told by the mapper's backward that grad[lo:hi] is final for this step
+        self.grad_listeners: List = []
+
+    def range_of(self, *names: str) -> Tuple[int, int]:
+        """[lo, hi) of the flat buffers spanned by the named parameters (contiguous in the layout when they belong to one layer)."""
+        los = [self.offsets[n][0] for n in names]
+        his = [self.offsets[n][0] + int(math.prod(self.offsets[n][1])) for n in names]
+        return min(los), max(his)
+
+    def wait_ready(self, lo: int = 0, hi: Optional[int] = None) -> None:
+        """Make the current stream wait for every pending update that overlaps [lo, hi) (no-op without a pipelined optimiser)."""
+        if not self._ready:
+            return
+        hi = self.numel if hi is None else hi
+        keep = []
+        for l, h, ev in self._ready:
+            if l < hi and lo < h:
+                torch.cuda.current_stream().wait_event(ev)
+            else:
+                keep.append((l, h, ev))
+        self._ready = keep
+
+    def notify_grad(self, lo: int, hi: int) -> None:
+        for cb in self.grad_listeners:
+            cb(lo, hi)
 
     def layout_tag(self) -> str:
         """Digest of the flat layout (names, offsets, shapes, total length): optimiser moments are raw flat buffers, so a checkpoint
@@ -148,6 +176,12 @@ class MLP(_MapperBase):
         self.dp_group = None
         self.dp_factor_exchange = False
 
+    def update_chunks(self) -> List[Tuple[int, int]]:
+        """Ranges of the flat buffers in the order the forward reads them (``FusedAdamW.step(chunks=...)``)."""
+        fl = self.flat
+        a, b = fl.range_of("model.0.weight"), fl.range_of("model.2.weight")
+        return _cover(fl, [(0, fl.small_numel), a, b])
+
     def forward(self, x: Tensor) -> Tensor:
         """``x``: [..., D] float -> [..., E*L] in the compute dtype (differentiable w.r.t. the parameters)."""
         lead = x.shape[:-1]
@@ -163,7 +197,10 @@ class _MLPFunction(torch.autograd.Function):
         fl, T = mod.flat, mod.dtype
         xT = _to_compute(x, T)
         u = torch.empty((xT.shape[0], mod.sizes[1]), device=xT.device, dtype=T)
+        fl.wait_ready(0, fl.small_numel)
+        fl.wait_ready(*fl.range_of("model.0.weight"))
         h = ops.gemm(xT, fl.w("model.0.weight"), bias=fl.f("model.0.bias"), act="tanh", aux_out=u)
+        fl.wait_ready()
         y = ops.gemm(h, fl.w("model.2.weight"), bias=fl.f("model.2.bias"))
         ctx.mod = mod
         ctx.save_for_backward(xT, u, h)
@@ -188,6 +225,7 @@ class _MLPFunction(torch.autograd.Function):
         # layer 2: dW2[N,K] = dy^T h ; db2 = colsum(dy) ; dh = (dy W2) * tanh'(u)
         _wgrad(dy_w, h_w, fl.g("model.2.weight"), acc)
         ops.colsum(dy_w, fl.g("model.2.bias"), acc)
+        fl.notify_grad(*fl.range_of("model.2.weight"))
         # dh = (dy W2) * tanh'(u): W2 is [N=E*L, K=H] (k-contiguous for the forward); its dgrad sums over N, so stream a
         # transposed copy (one HBM pass) through the k-contiguous kernels instead of transposing tile by tile in LDS
         w2 = fl.w("model.2.weight")
@@ -201,9 +239,24 @@ class _MLPFunction(torch.autograd.Function):
         dh_w, x_w = (gather(dh), gather(xT)) if gather else (dh, xT)
         _wgrad(dh_w, x_w, fl.g("model.0.weight"), acc)
         ops.colsum(dh_w, fl.g("model.0.bias"), acc)
+        fl.notify_grad(0, fl.numel)
         fl.grad_live = True
         mod.attach_grads()
         return (None, None) + (None,) * len(mod._names)
+
+
+def _cover(fl: FlatParams, ranges: List[Tuple[int, int]]) -> List[Tuple[int, int]]:
+    """``ranges`` (in use order) completed to a partition of [0, numel): padding gaps and anything not named go to the end."""
+    ranges = [r for r in ranges if r[1] > r[0]]
+    covered = sorted(ranges)
+    rest, at = [], 0
+    for lo, hi in covered:
+        if lo > at:
+            rest.append((at, lo))
+        at = max(at, hi)
+    if at < fl.numel:
+        rest.append((at, fl.numel))
+    return ranges + rest
 
 
 def _to_compute(x: Tensor, T: torch.dtype) -> Tensor:
@@ -272,6 +325,17 @@ class TransformerMapper(_MapperBase):
         self._adopt(flat, "", dict(self.named_parameters()))
         self.dtype = dtype
 
+    def layer_range(self, i: int) -> Tuple[int, int]:
+        """[lo, hi) of layer i's matrices in the flat buffers (contiguous: the 1-D parameters live in the leading small region)."""
+        p = f"transformer.layers.{i}."
+        return self.flat.range_of(p + "attn.to_queries.weight", p + "attn.to_keys_values.weight", p + "attn.project.weight",
+                                  p + "mlp.fc1.weight", p + "mlp.fc2.weight")
+
+    def update_chunks(self) -> List[Tuple[int, int]]:
+        """Ranges of the flat buffers in the order the forward reads them: 1-D parameters, ``linear`` + ``prefix_const``, layer 0 .. n - 1."""
+        fl = self.flat
+        return _cover(fl, [(0, fl.small_numel), fl.range_of("linear.weight", "prefix_const")] + [self.layer_range(i) for i in range(self.num_layers)])
+
     def forward(self, x: Tensor) -> Tensor:
         """``x``: [B, D] (or [B,1,1,D]) -> the mapper's whole residual stream cast to the compute dtype,
         ``[B, clip_length + L, E]``; the caller reads rows ``[:, clip_length:]`` (clipcap.py:220)."""
@@ -289,6 +353,8 @@ class _TransformerMapperFunction(torch.autograd.Function):
         B, CL, L, E, H = x.shape[0], mod.clip_length, mod.prefix_length, mod.E, mod.HEADS
         N, hd = CL + L, E // H
         xT = _to_compute(x, T)
+        fl.wait_ready(0, fl.small_numel)
+        fl.wait_ready(*fl.range_of("linear.weight", "prefix_const"))
         lin = ops.gemm(xT, fl.w("linear.weight"), bias=fl.f("linear.bias"))          # [B, CL*E]
         # rows of the stream: clip rows come from `lin` viewed [B*CL, E], const rows from prefix_const
         idx = torch.arange(N, device=x.device, dtype=torch.int32)
@@ -298,6 +364,7 @@ class _TransformerMapperFunction(torch.autograd.Function):
         tape = []
         for i in range(mod.num_layers):
             p = f"transformer.layers.{i}."
+            fl.wait_ready(*mod.layer_range(i))                # a pipelined optimiser may still be updating the later layers
             a, m1, r1 = ops.layernorm_fwd(h, fl.f(p + "norm1.weight"), fl.f(p + "norm1.bias"), 1e-5, T, save_stats=True)
             q = ops.gemm(a, fl.w(p + "attn.to_queries.weight"))
             kv = ops.gemm(a, fl.w(p + "attn.to_keys_values.weight"))
@@ -308,6 +375,7 @@ class _TransformerMapperFunction(torch.autograd.Function):
             h2 = ops.gemm(f1, fl.w(p + "mlp.fc2.weight"), bias=fl.f(p + "mlp.fc2.bias"), residual=h1, out_f32=True)
             tape.append((h, m1, r1, a, q, kv, ctxv, lse, h1, m2, r2, a2, f1))
             h = h2
+        fl.wait_ready()
         out = ops.cast_rows(h, T) if T != torch.float32 else h
         ctx.mod, ctx.tape, ctx.src, ctx.xT = mod, tape, src, xT
         ctx.dims = (B, CL, L, E, H, N, hd)
@@ -360,11 +428,13 @@ class _TransformerMapperFunction(torch.autograd.Function):
             if not acc:
                 g1w.zero_(); g1b.zero_()
             dh = ops.layernorm_bwd(h, as_T(da), fl.f(p + "norm1.weight"), m1, r1, dres=dh1, dgamma=g1w, dbeta=g1b, out=dh1)
+            fl.notify_grad(*mod.layer_range(i))               # this layer's weight gradients are final: a sharded exchange may start on them
         # stream assembly: prefix_const rows (sum over batch) and the linear projection rows
         ops.colsum(dh.view(B, N * E)[:, CL * E:], fl.g("prefix_const").view(L * E), acc)
         dlin = ops.embed_assemble_bwd(ctx.src, dh, B * CL, T).view(B, CL * E)
         _wgrad(dlin, ctx.xT, fl.g("linear.weight"), acc)
         ops.colsum(dlin, fl.g("linear.bias"), acc)
+        fl.notify_grad(0, fl.numel)
         fl.grad_live = True
         mod.attach_grads()
         return (None, None) + (None,) * len(mod._names)

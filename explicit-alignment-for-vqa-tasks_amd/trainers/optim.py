@@ -21,19 +21,40 @@ class FusedAdamW:
         self.v = torch.zeros_like(flat.master)
         self.step_count = 0
 
-    def step(self, grad_scale: float = 1.0) -> None:
+    def step(self, grad_scale: float = 1.0, chunks=None) -> None:
+        """``chunks`` (``mapper.update_chunks()``: a partition of the flat buffers in the order the forward reads them): the update runs
+        chunk by chunk on the optimiser's own stream and leaves one event per chunk with the parameters (``FlatParams.wait_ready``), so the
+        next forward starts on the first layer while the later layers are still being updated - AdamW is HBM-bound (30 B / parameter),
+        the mapper's GEMMs are not.  Elementwise arithmetic: the result is bit-equal to the one-launch update."""
         g = self.param_groups[0]
         self.step_count += 1
-        shadow = None if self.flat.shadow is self.flat.master else self.flat.shadow
-        ops.adamw(self.flat.master, self.flat.grad, self.m, self.v, self.step_count, g["lr"], g["betas"][0], g["betas"][1],
-                  g["eps"], g["weight_decay"], grad_scale, shadow=shadow)
-        self.flat.mark_shadow_fresh()
+        fl = self.flat
+        lowp = fl.shadow is not fl.master
+        kw = dict(step=self.step_count, lr=g["lr"], beta1=g["betas"][0], beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"],
+                  grad_scale=grad_scale)
+        if chunks and fl.master.is_cuda:
+            if sorted(chunks)[0][0] != 0 or sum(h - l for l, h in chunks) != fl.numel:
+                raise ValueError("chunks must partition the flat parameter buffer")
+            if getattr(self, "_stream", None) is None:
+                self._stream = torch.cuda.Stream()
+            fl.wait_ready()                                          # (a previous pipelined update nobody has waited for yet)
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                for lo, hi in chunks:
+                    ops.adamw(fl.master[lo:hi], fl.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], shadow=fl.shadow[lo:hi] if lowp else None, **kw)
+                    ev = torch.cuda.Event()
+                    ev.record(self._stream)
+                    fl._ready.append((lo, hi, ev))
+        else:
+            ops.adamw(fl.master, fl.grad, self.m, self.v, shadow=fl.shadow if lowp else None, **kw)
+        fl.mark_shadow_fresh()
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         """No memset: the next backward overwrites the flat gradient instead of accumulating."""
         self.flat.grad_live = False
 
     def state_dict(self):
+        self.flat.wait_ready()
         return dict(step=self.step_count, m=self.m, v=self.v, param_groups=self.param_groups, layout=self.flat.layout_tag())
 
     def load_state_dict(self, sd) -> None:
@@ -136,10 +157,18 @@ class ShardedAdamW:
     ``adamw`` is the update kernel (``ops.adamw``; the CPU tests inject a torch restatement - the product path has no CPU fallback)."""
 
     def __init__(self, flat, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, *, group=None,
-                 n_buckets: int = 4, adamw=None, collectives_in_group_of_one: bool = False, synchronous: Optional[bool] = None):
+                 n_buckets: int = 4, adamw=None, collectives_in_group_of_one: bool = False, synchronous: Optional[bool] = None,
+                 grad_transport: Optional[torch.dtype] = None):
         """``synchronous`` (default: the environment variable ``EAVQA_DP_SYNC=1``): the blocking order of round 2 - reduce-scatter,
         AdamW, all-gather bucket by bucket, every collective waited for before the next call - as a fallback should the
-        asynchronous issue order (never run on more than one GPU) misbehave on a real RCCL group; same arithmetic, same result."""
+        asynchronous issue order (never run on more than one GPU) misbehave on a real RCCL group; same arithmetic, same result.
+        ``grad_transport=torch.bfloat16``: the matrix gradients travel in bf16 (4 instead of 6 B / parameter over xGMI: the bucket is
+        cast before its reduce-scatter, the summed shard cast back before AdamW); the sum itself is then rounded to 8 significant
+        bits per hop - bounded in tests/test_data_parallel.py, off by default.
+        ``arm()`` before a backward lets the reduce-scatters start DURING it: the mapper's backward reports every layer whose weight
+        gradients are final (``FlatParams.notify_grad``) and each bucket those reports cover completely is put on the wire at once, in
+        backward order; ``start()`` then issues what is left.  Same collectives on the same data: bit-equal to the exchange after
+        ``backward()`` (the north_star's "all-reduce overlapped with backward")."""
         import os
         import torch.distributed as dist
         self.synchronous = (os.environ.get("EAVQA_DP_SYNC", "0") == "1") if synchronous is None else bool(synchronous)
@@ -162,6 +191,13 @@ class ShardedAdamW:
         self.m = torch.zeros(n_buckets * self.piece, device=dev)
         self.v = torch.zeros(n_buckets * self.piece, device=dev)
         self.gshard = torch.empty(n_buckets * self.piece, device=dev)
+        if grad_transport not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("grad_transport must be None / float32 / bfloat16")
+        self.transport = None if grad_transport in (None, torch.float32) else grad_transport
+        if self.transport is not None:
+            self.g16 = torch.empty(n_buckets * self.world * self.piece, device=dev, dtype=self.transport)
+            self.gshard16 = torch.empty(n_buckets * self.piece, device=dev, dtype=self.transport)
+        self._armed, self._listening, self._rs, self._covered = False, False, {}, []
         self.step_count = 0
         # a group of one needs no collectives; `collectives_in_group_of_one` issues them anyway (the RCCL path on a one-GPU box)
         self.multi = self.world > 1 or (collectives_in_group_of_one and dist.is_initialized())
@@ -178,6 +214,58 @@ class ShardedAdamW:
         lo = self.small + b * self.world * self.piece
         return lo, lo + self.world * self.piece, lo + self.rank * self.piece
 
+    # ---- reduce-scatter of one bucket (asynchronous); `early`: from inside the backward, behind what the current stream holds
+    def _issue_rs(self, b: int, early: bool = False) -> None:
+        import torch.distributed as dist
+        fl = self.flat
+        lo, hi, _ = self._bucket(b)
+
+        def go():
+            src, dst = fl.grad[lo:hi], self.gshard[b * self.piece:(b + 1) * self.piece]
+            if self.transport is not None:
+                src = self.g16[lo - self.small:hi - self.small]
+                if fl.grad.is_cuda:
+                    ops.cast_rows(fl.grad[lo:hi].view(1, hi - lo), self.transport, out=src.view(1, hi - lo))
+                else:
+                    src.copy_(fl.grad[lo:hi])
+                dst = self.gshard16[b * self.piece:(b + 1) * self.piece]
+            self._rs[b] = dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+        if early and self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                if not self._rs:
+                    self._e0_early = torch.cuda.Event(enable_timing=True)
+                    self._e0_early.record(self.stream)
+                go()
+        else:
+            go()
+
+    def arm(self) -> None:
+        """Call before the backward whose gradients the next ``start()`` exchanges (the LAST micro-batch of an accumulation window)."""
+        if self.synchronous or not self.multi:
+            return
+        if not self._listening:
+            self.flat.grad_listeners.append(self._on_grad)
+            self._listening = True
+        self._armed, self._rs, self._covered, self._e0_early = True, {}, [0] * self.n_buckets, None
+
+    def _on_grad(self, lo: int, hi: int) -> None:
+        if not self._armed:
+            return
+        for b in reversed(range(self.n_buckets)):                 # the backward completes the flat buffer from its end
+            if b in self._rs:
+                continue
+            blo, bhi, _ = self._bucket(b)
+            if lo <= blo and hi >= bhi:
+                self._covered[b] = bhi - blo
+            else:
+                self._covered[b] += max(0, min(hi, bhi) - max(lo, blo))
+            if self._covered[b] >= bhi - blo:
+                self._issue_rs(b, early=True)
+
     def _run(self, grad_scale: float) -> None:
         import torch.distributed as dist
         fl, g = self.flat, self.param_groups[0]
@@ -193,7 +281,7 @@ class ShardedAdamW:
         w_small = None
         if self.small and multi:
             w_small = dist.all_reduce(fl.grad[:self.small], op=dist.ReduceOp.SUM, group=self.group, async_op=not self.synchronous)
-        rs = []
+        self._armed = False
         if multi and self.synchronous:
             for b in range(self.n_buckets):
                 lo, hi, mine = self._bucket(b)
@@ -209,15 +297,16 @@ class ShardedAdamW:
             return
         if multi:
             for b in range(self.n_buckets):
-                lo, hi, _ = self._bucket(b)
-                rs.append(dist.reduce_scatter_tensor(self.gshard[b * self.piece:(b + 1) * self.piece], fl.grad[lo:hi], op=dist.ReduceOp.SUM,
-                                                     group=self.group, async_op=True))
+                if b not in self._rs:                             # (armed: some - or all - are already on the wire since the backward)
+                    self._issue_rs(b)
         ag = []
         for b in range(self.n_buckets):
             lo, hi, mine = self._bucket(b)
             if multi:
-                rs[b].wait()
+                self._rs[b].wait()
                 gs = self.gshard[b * self.piece:(b + 1) * self.piece]
+                if self.transport is not None:
+                    gs.copy_(self.gshard16[b * self.piece:(b + 1) * self.piece])      # dtype-converting copy of 1 / world of the bucket
             else:
                 gs = fl.grad[lo:hi]
             self.adamw(fl.master[mine:mine + self.piece], gs, self.m[b * self.piece:(b + 1) * self.piece], self.v[b * self.piece:(b + 1) * self.piece],
@@ -231,6 +320,7 @@ class ShardedAdamW:
             self.adamw(fl.master[:self.small], fl.grad[:self.small], self.m_small, self.v_small, shadow=fl.shadow[:self.small] if lowp else None, **kw)
         for w in ag:
             w.wait()
+        self._rs = {}
         self._master_stale = multi and lowp          # non-owned master shards are not updated in bf16-operand mode: gather_master()
         fl.mark_shadow_fresh()
 
@@ -242,9 +332,10 @@ class ShardedAdamW:
             with torch.cuda.stream(self.stream):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self.stream)
+                early = getattr(self, "_e0_early", None) if self._rs else None
                 self._run(scale)
                 e1.record(self.stream)
-                self._ev = (e0, e1)
+                self._ev = (early or e0, e1)                      # from the first reduce-scatter (possibly issued inside the backward)
         else:
             self._run(scale)
         self._busy = True

@@ -424,3 +424,44 @@ def test_decode_fast_path_logits_match_full_forward_bf16(arch, B):
             break
         raw = src[:, S].contiguous()                                       # teacher-forced next token
         logits = dec._decode_step(lm, cache, raw, pos[:, S].contiguous(), mask, B, S, S_max)
+
+
+@pytest.mark.parametrize("mapping_type", ["mlp", "transformer"])
+def test_pipelined_adamw_is_bit_equal_and_the_forward_waits_per_layer(mapping_type):
+    """``FusedAdamW.step(chunks=mapper.update_chunks())``: the update runs chunk by chunk on the optimiser's stream and the mapper's next
+    forward waits for the ranges it reads (``FlatParams.wait_ready``) - same parameters, bit for bit, as the one-launch update after three
+    training steps, for both mappers; the chunks partition the flat buffer in forward order."""
+    from eavqa_amd.models.clipcap import ClipCaptionPrefix
+    from eavqa_amd.models.lm import FrozenCausalLM, LMConfig, random_init_state_dict
+    from eavqa_amd.trainers.optim import FusedAdamW
+    cfg = LMConfig("gpt2", 2, 4, 64, 256, 320, 64, 1e-5, "gelu_new", 319, None)
+    sd = random_init_state_dict(cfg, 3, "cpu")
+    g = torch.Generator().manual_seed(5)
+    B, T, D, L = 6, 12, 24, 4
+    ids = torch.randint(3, 300, (B, T), generator=g)
+    mask = torch.ones(B, T, dtype=torch.long)
+    labels = ids.clone()
+    prefix = torch.randn(B, D, generator=g)
+    finals = []
+    for pipelined in (False, True):
+        lm = FrozenCausalLM(cfg, sd, torch.bfloat16, DEV)
+        torch.manual_seed(1)
+        model = ClipCaptionPrefix(prefix_length=L, clip_length=L, prefix_size=D, num_layers=3, mapping_type=mapping_type, lm=lm, dtype=torch.bfloat16,
+                                  device=DEV).train()
+        fl = model.clip_project.flat
+        chunks = model.clip_project.update_chunks()
+        assert sorted(chunks)[0][0] == 0 and sum(h - l for l, h in chunks) == fl.numel and chunks[0] == (0, fl.small_numel)
+        spans = sorted(chunks)
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))          # a partition: no gap, no overlap
+        opt = FusedAdamW(fl, lr=1e-2)
+        for _ in range(3):
+            out = model(question_tokens=ids, prefix=prefix, question_mask=mask, labels=labels)
+            out.loss.backward()
+            opt.step(chunks=chunks if pipelined else None)
+            opt.zero_grad()
+            if pipelined:
+                assert fl._ready                                            # the update is pending until a forward (or wait_ready) takes it
+        fl.wait_ready()
+        torch.cuda.synchronize()
+        finals.append((fl.master.clone(), fl.shadow.clone(), float(out.loss.item())))
+    assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1]) and finals[0][2] == finals[1][2]
