@@ -104,7 +104,7 @@ class Stepper:
     Every step performs one forward/backward and one optimiser update, and one encode - except the very first step of a run,
     which also encodes its own batch to fill the pipeline (untimed: it falls into the warm-up)."""
 
-    def __init__(self, vit, model, opt, batch, pad, sync, overlap_vit=True, pipelined_update=True):
+    def __init__(self, vit, model, opt, batch, pad, sync, overlap_vit=True, pipelined_update=False):
         self.vit, self.model, self.opt, self.batch, self.pad, self.sync = vit, model, opt, batch, pad, sync
         self.pending_update = False
         # AdamW chunk by chunk on its own stream, the mapper's forward waiting layer by layer (FusedAdamW.step(chunks=...)): the update is
@@ -383,7 +383,7 @@ def t0_cc_train_leg(dtype_name, steps, warmup, device, args):
     batch = {k: v.to(device) for k, v in batch.items()}
     batch["question_lengths"], batch["label_count"] = None, None
     sync = GradSync(vct0.clip_project.flat.grad, 1, exchange=True)
-    stepper = Stepper(vit, model, opt, batch, c.pad_token_id, sync, overlap_vit=not args.no_overlap, pipelined_update=not args.no_pipelined_update)
+    stepper = Stepper(vit, model, opt, batch, c.pad_token_id, sync, overlap_vit=not args.no_overlap, pipelined_update=args.pipelined_update)
     for _ in range(warmup):
         stepper.step()
     stepper.flush()
@@ -508,7 +508,7 @@ def train_leg(workload, dtype_name, steps, warmup, rank, world, device, args, lo
         sync = opt
     else:
         sync = GradSync(flat.grad, world, exchange=not factors)
-    stepper = Stepper(vit, model, opt, batch, pad, sync, overlap_vit=not args.no_overlap, pipelined_update=not args.no_pipelined_update)
+    stepper = Stepper(vit, model, opt, batch, pad, sync, overlap_vit=not args.no_overlap, pipelined_update=args.pipelined_update)
 
     def barrier():
         torch.cuda.synchronize()
@@ -605,8 +605,10 @@ def main():
                     help="skip the short cfg3 (bf16) and cfg5 (fp8) training legs that the default cfg2 run reports under 'extra'")
     ap.add_argument("--grad-transport", choices=["f32", "bf16"], default="f32",
                     help="N > 1, sharded exchange: dtype of the gradient on the wire (bf16: 4 instead of 6 B / parameter, the sum rounded per hop)")
-    ap.add_argument("--no-pipelined-update", action="store_true",
-                    help="one AdamW launch on the main stream in front of the mapper's forward (default: chunk by chunk on its own stream, the forward waits per layer)")
+    ap.add_argument("--pipelined-update", action="store_true",
+                    help="AdamW chunk by chunk on its own stream, the mapper's forward waiting per layer (FusedAdamW.step(chunks=...)); default: one "
+                         "launch on the main stream in front of the forward.  Measured equal on one GPU (cfg2 4763 / 4767, cfg5 525.0 / 523.7 "
+                         "samples/s: the HBM-bound update and the GEMMs it would hide under slow each other down)")
     ap.add_argument("--no-t0", action="store_true",
                     help="skip the two T0_3B legs (the reference's headline model: few-shot generate and CC mapper training) reported under 'extra'")
     ap.add_argument("--hbm-bytes-out", default=None,

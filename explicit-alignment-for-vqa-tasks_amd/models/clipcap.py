@@ -332,9 +332,10 @@ class TransformerMapper(_MapperBase):
                                   p + "mlp.fc1.weight", p + "mlp.fc2.weight")
 
     def update_chunks(self) -> List[Tuple[int, int]]:
-        """Ranges of the flat buffers in the order the forward reads them: 1-D parameters, ``linear`` + ``prefix_const``, layer 0 .. n - 1."""
+        """Ranges of the flat buffers in the order the forward reads them: 1-D parameters, ``linear``, ``prefix_const``, layer 0 .. n - 1
+        (in the flat layout ``prefix_const`` - a direct parameter - comes first and ``linear.weight`` last)."""
         fl = self.flat
-        return _cover(fl, [(0, fl.small_numel), fl.range_of("linear.weight", "prefix_const")] + [self.layer_range(i) for i in range(self.num_layers)])
+        return _cover(fl, [(0, fl.small_numel), fl.range_of("linear.weight"), fl.range_of("prefix_const")] + [self.layer_range(i) for i in range(self.num_layers)])
 
     def forward(self, x: Tensor) -> Tensor:
         """``x``: [B, D] (or [B,1,1,D]) -> the mapper's whole residual stream cast to the compute dtype,
@@ -354,7 +355,8 @@ class _TransformerMapperFunction(torch.autograd.Function):
         N, hd = CL + L, E // H
         xT = _to_compute(x, T)
         fl.wait_ready(0, fl.small_numel)
-        fl.wait_ready(*fl.range_of("linear.weight", "prefix_const"))
+        fl.wait_ready(*fl.range_of("linear.weight"))
+        fl.wait_ready(*fl.range_of("prefix_const"))
         lin = ops.gemm(xT, fl.w("linear.weight"), bias=fl.f("linear.bias"))          # [B, CL*E]
         # rows of the stream: clip rows come from `lin` viewed [B*CL, E], const rows from prefix_const
         idx = torch.arange(N, device=x.device, dtype=torch.int32)
