@@ -987,6 +987,23 @@ extern "C" int eavqa_attention_bwd_rel(int dtype, int B, int H, int Sq, int Sk, 
     p.bsq = Sq; p.bsk = Sk; p.ld_mask = Sk; p.stat_ld = Sq;
     p.rel_bias = rel_bias; p.rel_ld = rel_ld; p.rel_zero = rel_zero;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // bf16 at an MFMA head size: the matrix-core backward kernels recompute P with the bias added (round 4; the vector-ALU kernels below
+    // were 12 % of a T0_3B training step).  Without a bias this is eavqa_attention_bwd (T5's cross-attention).
+    if (dtype == EAVQA_BF16 && eavqa_attn_mfma::supported(hd) && !(ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 8 || lddk % 8 || lddv % 8) &&
+        eavqa_aligned16(q) && eavqa_aligned16(k) && eavqa_aligned16(v) && eavqa_aligned16(o) && eavqa_aligned16(d_o) && eavqa_aligned16(dq) &&
+        eavqa_aligned16(dk) && eavqa_aligned16(dv)) {
+        eavqa_attn_mfma::Params m = {};
+        m.q = q; m.k = k; m.v = v; m.o = o; m.d_o = d_o; m.dq = dq; m.dk = dk; m.dv = dv;
+        m.ldq = ldq; m.ldk = ldk; m.ldv = ldv; m.ldo = ldo; m.lddo = lddo; m.lddq = lddq; m.lddk = lddk; m.lddv = lddv;
+        m.key_mask = key_mask; m.ld_mask = Sk; m.cu = nullptr; m.lse = const_cast<float*>(lse); m.delta = delta;
+        m.B = B; m.H = H; m.Sq = Sq; m.Sk = Sk; m.hd = hd; m.causal = causal; m.stat_ld = Sq;
+        m.bsq = Sq; m.bsk = Sk; m.scale = scale;
+        m.rel_bias = rel_bias; m.rel_ld = rel_ld; m.rel_zero = rel_zero;
+        if (Sq <= eavqa_attn_mfma::TILE && Sk <= eavqa_attn_mfma::TILE) return eavqa_attn_mfma::run(3, m, s);
+        rc = eavqa_attn_mfma::run(1, m, s);
+        if (rc) return rc;
+        return eavqa_attn_mfma::run(2, m, s);
+    }
     rc = dtype == EAVQA_F32 ? dispatch<float>(K_DQ, p, s) : dispatch<bf16_t>(K_DQ, p, s);
     if (rc) return rc;
     return dtype == EAVQA_F32 ? dispatch<float>(K_DKV, p, s) : dispatch<bf16_t>(K_DKV, p, s);

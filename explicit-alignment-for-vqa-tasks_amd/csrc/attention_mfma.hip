@@ -38,6 +38,17 @@ struct Params {
     const float* rel_bias; int64_t rel_ld; int rel_zero;
 };
 
+// T5's additive relative-position bias of (head h, key position, query position counted from the end of the keys): 0 without a table;
+// entries outside the table are clamped (they belong to masked positions only).  Used by the forward AND, since round 4, by the
+// backward kernels (the frozen T5's dgrad recomputes P = softmax(q k^T scale + bias): T0_3B training spent 12 % of its step in the
+// vector-ALU backward kernels because only they knew the bias).
+__device__ __forceinline__ float rel_bias_at(const Params& p, int h, int key, int qpos) {
+    if (!p.rel_bias) return 0.f;
+    const int idx = min(max(key - qpos + p.rel_zero, 0), (int)p.rel_ld - 1);
+    return p.rel_bias[(int64_t)h * p.rel_ld + idx];
+}
+
+
 constexpr int TILE = 64;
 
 // s_waitcnt immediate that waits for vmcnt <= n only (lgkmcnt / expcnt untouched)
@@ -536,7 +547,7 @@ __global__ __launch_bounds__(256) void bwd_dq_kernel(Params p) {
                 const int kk = 16 * f + 4 * g + r;
                 const bool exists = k0 + kk < p.Sk;
                 const bool vis = exists && valid[kk] && (!p.causal || (k0 + kk) <= qi + off);
-                const float pj = exists ? __expf((vis ? st[f][r] * p.scale : -FLT_MAX) - lse) : 0.f;
+                const float pj = exists ? __expf((vis ? st[f][r] * p.scale + rel_bias_at(p, h, k0 + kk, qi + off) : -FLT_MAX) - lse) : 0.f;
                 st[f][r] = pj * (dp[f][r] - delta) * p.scale;      // dS^T
             }
         tile_accumulate<KS, D16>(dq, Ks, st, x, g);
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(256) void bwd_dkv_kernel(Params p) {
                 const int qq = 16 * f + 4 * g + r;          // query within the tile
                 const bool exists = q0 + qq < p.Sq;
                 const bool vis = exists && kvalid && (!p.causal || kj <= (q0 + qq) + off);
-                const float pj = exists ? __expf((vis ? sc[f][r] * p.scale : -FLT_MAX) - stats[qq]) : 0.f;
+                const float pj = exists ? __expf((vis ? sc[f][r] * p.scale + rel_bias_at(p, h, kj, q0 + qq + off) : -FLT_MAX) - stats[qq]) : 0.f;
                 sc[f][r] = pj;                                                   // P
                 dp[f][r] = pj * (dp[f][r] - stats[TILE + qq]) * p.scale;        // dS
             }
@@ -686,7 +697,7 @@ __global__ __launch_bounds__(256) void bwd_fused_kernel(Params p) {
             const int qq = 16 * f + 4 * g + r;
             const bool exists = qq < p.Sq;
             const bool vis = exists && kvalid && (!p.causal || item <= qq + off);
-            const float pj = exists ? __expf((vis ? sc[f][r] * p.scale : -FLT_MAX) - stats[qq]) : 0.f;
+            const float pj = exists ? __expf((vis ? sc[f][r] * p.scale + rel_bias_at(p, h, item, qq + off) : -FLT_MAX) - stats[qq]) : 0.f;
             sc[f][r] = pj;                                                   // P
             dp[f][r] = pj * (dp[f][r] - stats[TILE + qq]) * p.scale;        // dS
             *reinterpret_cast<bf16_t*>(DSs + qq * DS_PITCH + item * 2) = (bf16_t)(kactive ? dp[f][r] : 0.f);
@@ -836,7 +847,7 @@ __global__ __launch_bounds__(256, 5) void bwd_fused64_kernel(Params p, int R) {
             const int qq = 16 * f + 4 * g + r;
             const bool exists = qq < p.Sq;
             const bool vis = exists && kvalid && (!p.causal || item <= qq + off);
-            const float pj = exists ? __expf((vis ? sc[f][r] * p.scale : -FLT_MAX) - stats[qq]) : 0.f;
+            const float pj = exists ? __expf((vis ? sc[f][r] * p.scale + rel_bias_at(p, h, item, qq + off) : -FLT_MAX) - stats[qq]) : 0.f;
             sc[f][r] = pj;                                                   // P
             dp[f][r] = pj * (dp[f][r] - stats[TILE + qq]) * p.scale;        // dS
             if (qq < R && item < TILE) *reinterpret_cast<bf16_t*>(DSs + ds_off(qq, item)) = (bf16_t)(kactive ? dp[f][r] : 0.f);
@@ -1137,7 +1148,7 @@ __global__ __launch_bounds__(256) void bwd_wide_kernel(Params p) {
             const int qq = 16 * f + 4 * g + r;
             const bool exists = qq < p.Sq;
             const bool vis = exists && kvalid && (!p.causal || item <= qq + off);
-            const float pj = exists ? __expf((vis ? sc[f][r] * p.scale : -FLT_MAX) - stats[qq]) : 0.f;
+            const float pj = exists ? __expf((vis ? sc[f][r] * p.scale + rel_bias_at(p, h, item, qq + off) : -FLT_MAX) - stats[qq]) : 0.f;
             sc[f][r] = pj;                                                   // P
             dp[f][r] = pj * (dp[f][r] - stats[TILE + qq]) * p.scale;        // dS
             *reinterpret_cast<bf16_t*>(DSs + qq * DS_PITCH + item * 2) = (bf16_t)(kactive ? dp[f][r] : 0.f);

@@ -444,7 +444,8 @@ int eavqa_gated_act_bwd(int dtype, int rows, int F, int act, const void* u, int6
                         void* du, int64_t lddu, void* stream);
 /* eavqa_attention_fwd / _bwd with T5's relative-position bias (HF:models/t5/modeling_t5.py:217-279, added to the unscaled scores,
  * :312-350): score(i, j) += rel_bias[h * rel_ld + (j - (i + Sk - Sq)) + rel_zero] (float32 table per head over key - query
- * offsets, at least -(Sk - 1) .. Sk - 1; NULL = no bias: the cross-attention).  No packed (cu_seqlens) form.  fp32 arithmetic. */
+ * offsets, at least -(Sk - 1) .. Sk - 1; NULL = no bias: the cross-attention).  No packed (cu_seqlens) form.  bfloat16 at head sizes 64 / 80 /
+ * 96 / 128: the matrix-core kernels, forward and backward; float32 (and other head sizes): fp32 arithmetic on the vector-ALU kernels. */
 int eavqa_attention_fwd_rel(int dtype, int B, int H, int Sq, int Sk, int hd, const void* q, int64_t ldq, const void* k, int64_t ldk,
                             const void* v, int64_t ldv, void* o, int64_t ldo, int64_t q_batch_rows, int64_t kv_batch_rows,
                             const int32_t* key_mask, int64_t ld_mask, int causal, float scale, const float* rel_bias,
