@@ -856,7 +856,7 @@ def step_roofline(vit, model, opt, batch, pad, sync, ops, workload="cfg2", dtype
     # runs, FETCH_SIZE x 2 on gfx950, KiB units; tools/pmc_traffic.py).  The file carries the digest of the GEMM sources it was
     # measured on: with other sources the figure is dropped, not reused.
     traffic, traffic_source = None, None
-    for rnd in ("round3", "round2"):
+    for rnd in ("round4", "round3", "round2"):
         tfile = os.path.join(ROOT, "profiles", f"{rnd}_gemm_traffic_{workload}_{dtype_name}.json")
         if os.path.exists(tfile):
             break
