@@ -97,6 +97,13 @@ class DecodeGemm(C.Structure):
                 ("out", ptr * 3), ("ld_out", i64 * 3), ("stats_out", ptr)]
 
 
+class GemmLn(C.Structure):
+    """``eavqa_gemm_ln_t``."""
+    _fields_ = [("copy_out", ptr), ("ld_copy", i64), ("stats_out", ptr), ("stats_ld", i32), ("ln_stats", ptr), ("ln_parts", i32),
+                ("ln_ld", i32), ("ln_cols", i32), ("ln_c", ptr), ("ln_eps", f32), ("mean_out", ptr), ("rstd_out", ptr)]
+
+
+SIGNATURES["eavqa_gemm_ln"] = SIGNATURES["eavqa_gemm"][:-1] + [C.POINTER(GemmLn), ptr]
 SIGNATURES["eavqa_gemm_decode_cols"] = [i32, i32, i32, i32, i32]
 SIGNATURES["eavqa_gemm_decode"] = [C.POINTER(DecodeGemm), ptr]
 SIGNATURES["eavqa_t5_decoder_step_workspace_bytes"] = [i32, i32, i32, i32, i32, i32]
@@ -109,6 +116,7 @@ SIGNATURES["eavqa_lm_block_forward"] = [i32, i32, C.POINTER(LMLayer), i32, i32, 
 
 # include/eavqa_test.h: the same entry points with an explicit kernel selector (tests and tools only)
 SIGNATURES["eavqa_gemm_ex"] = SIGNATURES["eavqa_gemm"] + [i32]
+SIGNATURES["eavqa_gemm_ln_ex"] = SIGNATURES["eavqa_gemm_ln"] + [i32]
 SIGNATURES["eavqa_attention_fwd_ex"] = SIGNATURES["eavqa_attention_fwd"] + [i32]
 SIGNATURES["eavqa_attention_bwd_ex"] = SIGNATURES["eavqa_attention_bwd"] + [i32]
 SIGNATURES["eavqa_gemm_splitk_ex"] = SIGNATURES["eavqa_gemm_splitk"] + [i32]

@@ -48,7 +48,17 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int group_n;                   // 256 x 256 kernel: tile columns per group of the in-XCD tile order (0 = m fastest)
     int vec_c, vec_aux, vec_res, vec_bias;   // 16-byte (8-byte for bf16) vector access allowed on C / aux / residual / bias
+    // -- eavqa_gemm_ln (LayerNorm of a frozen LM folded into its neighbours, include/eavqa.h) --
+    // producer side: a second copy of the result in the operand dtype and (sum, sum of squares) of every result row per 64-column slot
+    void* copy_out = nullptr; int64_t ld_copy = 0; int vec_copy = 0;
+    float* stats_out = nullptr; int stats_ld = 0;          // [M][stats_ld][2]; slots a tile does not own are written as zeros by the last tile column
+    // consumer side: A holds UN-normalised rows x; B holds W * gamma; C = rstd (alpha acc - mean c) + bias with (mean, rstd) from the row sums
+    const float* ln_stats = nullptr; int ln_parts = 0, ln_ld = 0;
+    const float* ln_c = nullptr; float ln_inv_n = 0.f, ln_eps = 0.f;
+    float* mean_out = nullptr; float* rstd_out = nullptr;  // [M], written by the tiles of column 0 (LayerNorm backward reads them)
 };
+constexpr int LN_ROWSTAT_BYTES = 2048;                 // (rstd, -rstd mean) of up to 256 tile rows, behind a kernel's ring / C tile in dynamic LDS
+inline int ln_lds(const GemmParams& p) { return p.ln_stats ? LN_ROWSTAT_BYTES : 0; }
 
 constexpr int BM = 128, BN = 128;
 constexpr int CS_PITCH = 132;                       // floats per row of the staged C tile
@@ -65,6 +75,40 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
     tn = wgid / p.tiles_m;
 }
 
+// eavqa_gemm_ln, consumer side: (rstd, -rstd mean) of the tile's rows from the producer's partial sums, once per tile.  Any subset of the
+// workgroup's threads may run it (tid in [0, nthreads)); a barrier lies between it and the epilogue in every kernel.
+__device__ __forceinline__ void ln_rowstat_fill(const GemmParams& p, float2* rowstat, int m0, int n0, int rows, int tid, int nthreads) {
+    if (!p.ln_stats) return;
+    for (int r = tid; r < rows; r += nthreads) {
+        const int m = min(m0 + r, p.M - 1);
+        const float2* q = reinterpret_cast<const float2*>(p.ln_stats) + (int64_t)m * p.ln_ld;
+        float s = 0.f, ss = 0.f;
+        if (((p.ln_ld | p.ln_parts) & 1) == 0 && (reinterpret_cast<uintptr_t>(p.ln_stats) & 15) == 0) {
+            // two slots per 16-byte load, four loads in flight (a row's slots are contiguous); slots past the end are re-read from the last
+            // pair and multiplied by zero, so the order of the additions does not depend on the slot count's remainder
+            const float4* q4 = reinterpret_cast<const float4*>(q);
+            const int n4 = p.ln_parts >> 1;
+            for (int i = 0; i < n4; i += 4) {
+                float4 t[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[k] = q4[min(i + k, n4 - 1)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float w = (i + k < n4) ? 1.f : 0.f;
+                    s += w * (t[k].x + t[k].z);
+                    ss += w * (t[k].y + t[k].w);
+                }
+            }
+        } else {
+            for (int i = 0; i < p.ln_parts; ++i) { const float2 t = q[i]; s += t.x; ss += t.y; }
+        }
+        const float mean = s * p.ln_inv_n;
+        const float rstd = 1.0f / sqrtf(fmaxf(ss * p.ln_inv_n - mean * mean, 0.f) + p.ln_eps);
+        rowstat[r] = make_float2(rstd, -rstd * mean);
+        if (n0 == 0 && m0 + r < p.M && p.mean_out) { p.mean_out[m] = mean; p.rstd_out[m] = rstd; }
+    }
+}
+
 // ---- epilogue shared by all kernels: Cs holds the 128x128 fp32 tile (pitch CS_PITCH) ----
 // MODE: 0 = no activation, 1 = forward activation, 2 = multiply by the activation derivative at aux_in.
 // FULL: the tile lies entirely inside C and every operand allows vector access: no bounds checks, 8/16-byte
@@ -72,20 +116,27 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
 // Geometry G: TPR threads cover one row of the staged tile (4 columns each), RPP rows per pass, NPASS passes, PITCH floats
 // per staged row.
 // ROWS < RPP * NPASS (tile widths that do not divide the block): threads beyond TPR * RPP idle, the last pass is cut at ROWS.
-template <int TPR_, int RPP_, int NPASS_, int PITCH_, int ROWS_ = RPP_ * NPASS_> struct EpiGeo {
+template <int TPR_, int RPP_, int NPASS_, int PITCH_, int ROWS_ = RPP_ * NPASS_, int LN_UNROLL_ = 4> struct EpiGeo {
     static constexpr int TPR = TPR_, RPP = RPP_, NPASS = NPASS_, PITCH = PITCH_, ROWS = ROWS_;
+    static constexpr int LN_UNROLL = LN_UNROLL_;      // passes in flight in the eavqa_gemm_ln form of the epilogue (1 where registers are short)
 };
 using EpiGeo128 = EpiGeo<32, 8, 16, CS_PITCH>;      // 128 x 128 tile, 256 threads
 
 // one row m, four consecutive columns n .. n + 3: v[] = the fp32 accumulators on entry
-template <typename T, int ACT, int MODE, bool FULL>
-__device__ __forceinline__ void epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], const float (&bias4)[4]) {
+template <typename T, int ACT, int MODE, bool FULL, bool LNX>
+__device__ __forceinline__ void epilogue_quad(const GemmParams& p, int m, int n, float (&v)[4], const float (&bias4)[4], const float2 rs,
+                                              const float (&c4)[4]) {
     const T* aux_in = reinterpret_cast<const T*>(p.aux_in);
     T* aux_out = reinterpret_cast<T*>(p.aux_out);
     const bool full = FULL || (n + 3 < p.N);
     const float al = p.row_scale ? p.alpha * p.row_scale[m] : p.alpha;
+    if (LNX && p.ln_stats) {                             // rstd (alpha acc - mean c[n]) + bias[n]
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = al * v[j] + bias4[j];
+        for (int j = 0; j < 4; ++j) v[j] = (al * rs.x) * v[j] + (bias4[j] + rs.y * c4[j]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = al * v[j] + bias4[j];
+    }
     if (aux_out) {
         T* q = aux_out + (int64_t)m * p.ld_aux + n;
         if (FULL || (full && p.vec_aux)) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
@@ -146,6 +197,13 @@ __device__ __forceinline__ void epilogue_quad(const GemmParams& p, int m, int n,
             for (int j = 0; j < 4; ++j)
                 if (n + j < p.N) elem<T>::st(q + j, v[j]);
     }
+    if (LNX && p.copy_out) {
+        T* q = reinterpret_cast<T*>(p.copy_out) + (int64_t)m * p.ld_copy + n;
+        if (full && p.vec_copy) elem<T>::st4(q, make_float4(v[0], v[1], v[2], v[3]));
+        else
+            for (int j = 0; j < 4; ++j)
+                if (n + j < p.N) elem<T>::st(q + j, v[j]);
+    }
 }
 
 template <bool FULL>
@@ -161,56 +219,113 @@ __device__ __forceinline__ void load_bias4(const GemmParams& p, int n, float (&b
     }
 }
 
-template <typename T, int ACT, int MODE, bool FULL, typename G>
-__device__ __forceinline__ void epilogue_body(const GemmParams& p, const float* Cs, int m0, int n0) {
+// LnArgs: where the tile's row statistics lie (eavqa_gemm_ln consumer side) and which of them this staged slab starts at
+struct LnArgs { const float2* rowstat; int row_base; };
+
+template <typename T, int ACT, int MODE, bool FULL, typename G, bool LNX>
+__device__ __forceinline__ void epilogue_body(const GemmParams& p, float* Cs, int m0, int n0, const LnArgs ln) {
     const int tid = threadIdx.x;
     if (G::ROWS != G::RPP * G::NPASS && tid >= G::TPR * G::RPP) return;
     const int c4 = (tid % G::TPR) * 4;
     const int n = n0 + c4;
-    float bias4[4];
+    float bias4[4], lc4[4] = {0.f, 0.f, 0.f, 0.f};
     load_bias4<FULL>(p, n, bias4);
-#pragma unroll 4
-    for (int pass = 0; pass < G::NPASS; ++pass) {
+    if (LNX && p.ln_stats) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (FULL || n + j < p.N) lc4[j] = p.ln_c[n + j];
+    }
+    auto one_pass = [&](int pass) {
         const int row = (tid / G::TPR) + pass * G::RPP;
         const int m = m0 + row;
-        if (G::ROWS != G::RPP * G::NPASS && row >= G::ROWS) continue;
-        if (!FULL && (m >= p.M || n >= p.N)) continue;
+        if (G::ROWS != G::RPP * G::NPASS && row >= G::ROWS) return;
+        if (!FULL && (m >= p.M || n >= p.N)) return;
         const float4 a = *reinterpret_cast<const float4*>(&Cs[row * G::PITCH + c4]);
         float v[4] = {a.x, a.y, a.z, a.w};
-        epilogue_quad<T, ACT, MODE, FULL>(p, m, n, v, bias4);
+        const float2 rs = (LNX && p.ln_stats) ? ln.rowstat[ln.row_base + row] : make_float2(1.f, 0.f);
+        epilogue_quad<T, ACT, MODE, FULL, LNX>(p, m, n, v, bias4, rs, lc4);
+        if (LNX && p.stats_out) {                           // the values as stored (before any rounding), zeros beyond column N, back into the staged tile
+            if (!FULL) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (n + j >= p.N) v[j] = 0.f;
+            }
+            *reinterpret_cast<float4*>(&Cs[row * G::PITCH + c4]) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    };
+    if constexpr (LNX && G::LN_UNROLL == 1) {               // (a literal count: the pragma does not take a dependent expression reliably)
+#pragma unroll 1
+        for (int pass = 0; pass < G::NPASS; ++pass) one_pass(pass);
+    } else {
+#pragma unroll 4
+        for (int pass = 0; pass < G::NPASS; ++pass) one_pass(pass);
     }
 }
 
-template <typename T, int ACT, int MODE, typename G>
-__device__ __forceinline__ void epilogue_mode(const GemmParams& p, const float* Cs, int m0, int n0) {
+// eavqa_gemm_ln, producer side: (sum, sum of squares) of the finished rows of this slab, one thread per row in column order (a fixed
+// summation order: bitwise reproducible), into the 64-column slots the tile covers - the whole sum in the first, zeros in the others -
+// and zeros into the slots behind the last tile column, so that a consumer adds all stats_ld slots without knowing the tile width.
+template <typename G>
+__device__ __forceinline__ void epilogue_row_sums(const GemmParams& p, const float* Cs, int m0, int n0) {
+    constexpr int COLS = G::TPR * 4;
+    static_assert(COLS >= 64 && COLS % 4 == 0, "a tile covers at least one 64-column slot");
+    __syncthreads();
+    const int cols = min(COLS, p.N - n0);
+    const int slot0 = n0 / 64, slot1 = (n0 + COLS < p.N) ? (n0 + COLS) / 64 : p.stats_ld;     // this tile owns slots [slot0, slot1)
+    for (int r = threadIdx.x; r < G::ROWS; r += blockDim.x) {
+        const int m = m0 + r;
+        if (m >= p.M) continue;
+        float s = 0.f, ss = 0.f;
+        for (int c = 0; c < cols; c += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(&Cs[r * G::PITCH + c]);
+            s += (t.x + t.y) + (t.z + t.w);
+            ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        }
+        float2* q = reinterpret_cast<float2*>(p.stats_out) + (int64_t)m * p.stats_ld;
+        q[slot0] = make_float2(s, ss);
+        for (int i = slot0 + 1; i < slot1; ++i) q[i] = make_float2(0.f, 0.f);
+    }
+}
+
+template <typename T, int ACT, int MODE, typename G, bool LNX>
+__device__ __forceinline__ void epilogue_mode(const GemmParams& p, float* Cs, int m0, int n0, const LnArgs ln) {
     constexpr int ROWS = G::ROWS, COLS = G::TPR * 4;
     const bool full_tile = (m0 + ROWS <= p.M) && (n0 + COLS <= p.N) && p.vec_c && (!(p.aux_in || p.aux_out) || p.vec_aux) &&
                            (!p.residual || p.vec_res) && (!p.bias || p.vec_bias);
-    if (full_tile) epilogue_body<T, ACT, MODE, true, G>(p, Cs, m0, n0);
-    else epilogue_body<T, ACT, MODE, false, G>(p, Cs, m0, n0);
+    if (full_tile) epilogue_body<T, ACT, MODE, true, G, LNX>(p, Cs, m0, n0, ln);
+    else epilogue_body<T, ACT, MODE, false, G, LNX>(p, Cs, m0, n0, ln);
+    if (LNX && p.stats_out) epilogue_row_sums<G>(p, Cs, m0, n0);
 }
 
 // block-uniform dispatch on the (runtime) activation id / mode: each combination gets its own straight-line body
-template <typename T, typename G = EpiGeo128>
-__device__ __forceinline__ void epilogue(const GemmParams& p, const float* Cs, int m0, int n0) {
+// LNX = false compiles the eavqa_gemm_ln paths out (the 1024-thread 256 x 256 kernel has 128 registers per lane: its plain form must not carry them)
+template <typename T, typename G = EpiGeo128, bool LNX = true>
+__device__ __forceinline__ void epilogue(const GemmParams& p, float* Cs, int m0, int n0, const LnArgs ln = LnArgs{nullptr, 0}) {
     const int mode = p.aux_in ? 2 : (p.act != EAVQA_ACT_NONE ? 1 : 0);
-    if (mode == 0) { epilogue_mode<T, EAVQA_ACT_NONE, 0, G>(p, Cs, m0, n0); return; }
+    if (mode == 0) { epilogue_mode<T, EAVQA_ACT_NONE, 0, G, LNX>(p, Cs, m0, n0, ln); return; }
     switch (p.act) {
         case EAVQA_ACT_TANH:
-            if (mode == 1) epilogue_mode<T, EAVQA_ACT_TANH, 1, G>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_TANH, 2, G>(p, Cs, m0, n0);
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_TANH, 1, G, LNX>(p, Cs, m0, n0, ln); else epilogue_mode<T, EAVQA_ACT_TANH, 2, G, LNX>(p, Cs, m0, n0, ln);
             break;
         case EAVQA_ACT_RELU:
-            if (mode == 1) epilogue_mode<T, EAVQA_ACT_RELU, 1, G>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_RELU, 2, G>(p, Cs, m0, n0);
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_RELU, 1, G, LNX>(p, Cs, m0, n0, ln); else epilogue_mode<T, EAVQA_ACT_RELU, 2, G, LNX>(p, Cs, m0, n0, ln);
             break;
         case EAVQA_ACT_GELU_NEW:
-            if (mode == 1) epilogue_mode<T, EAVQA_ACT_GELU_NEW, 1, G>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_GELU_NEW, 2, G>(p, Cs, m0, n0);
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_GELU_NEW, 1, G, LNX>(p, Cs, m0, n0, ln); else epilogue_mode<T, EAVQA_ACT_GELU_NEW, 2, G, LNX>(p, Cs, m0, n0, ln);
             break;
         case EAVQA_ACT_QUICK_GELU:
-            if (mode == 1) epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 1, G>(p, Cs, m0, n0); else epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 2, G>(p, Cs, m0, n0);
+            if (mode == 1) epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 1, G, LNX>(p, Cs, m0, n0, ln); else epilogue_mode<T, EAVQA_ACT_QUICK_GELU, 2, G, LNX>(p, Cs, m0, n0, ln);
             break;
         default:   // aux_in with act == none: derivative 1
-            epilogue_mode<T, EAVQA_ACT_NONE, 0, G>(p, Cs, m0, n0);
+            epilogue_mode<T, EAVQA_ACT_NONE, 0, G, LNX>(p, Cs, m0, n0, ln);
     }
+}
+
+// the call every kernel with registers to spare makes: the plain epilogue unless the launch carries eavqa_gemm_ln arguments (block-uniform)
+template <typename T, typename G = EpiGeo128>
+__device__ __forceinline__ void epilogue_any(const GemmParams& p, float* Cs, int m0, int n0, const LnArgs ln = LnArgs{nullptr, 0}) {
+    if (p.ln_stats || p.stats_out || p.copy_out) epilogue<T, G, true>(p, Cs, m0, n0, ln);
+    else epilogue<T, G, false>(p, Cs, m0, n0, ln);
 }
 
 // (Round 3 built a direct register -> global epilogue for the specialised tiles - operands swapped, B fragment rows permuted so that a
@@ -345,8 +460,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
                 const int col = wn * 64 + j * 16 + (lane & 15);
                 Cs[row * CS_PITCH + col] = acc[i][j][r];
             }
+    float2* rowstat = reinterpret_cast<float2*>(smem + CS_BYTES);          // present when launched with ln_lds(p) extra bytes
+    ln_rowstat_fill(p, rowstat, m0, n0, BM, tid, 256);
     __syncthreads();
-    epilogue<bf16_t>(p, Cs, m0, n0);
+    epilogue_any<bf16_t>(p, Cs, m0, n0, LnArgs{rowstat, 0});
 }
 
 
@@ -532,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
                 Cs[row * CS_PITCH + col] = acc[i][j][r];
             }
     __syncthreads();
-    epilogue<bf16_t>(p, Cs, m0, n0);
+    epilogue_any<bf16_t>(p, Cs, m0, n0);
 }
 #undef EAVQA_FAST_STEP
 
@@ -760,7 +877,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
                     }
         }
         __syncthreads();
-        epilogue<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>>(p, Cs, m0 + pass * G::PROWS, n0);
+        epilogue_any<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>>(p, Cs, m0 + pass * G::PROWS, n0);
         if (pass + 1 < WM / G::SP) __syncthreads();
     }
 }
@@ -820,7 +937,7 @@ constexpr int GOPER = GBM * GBK * 2;               // 32 KiB per operand per sta
 constexpr int GSTAGE = 2 * GOPER;                  // 64 KiB
 constexpr int GCS_PITCH = GBN + 4;                 // floats per staged C row
 constexpr int GLDS_BYTES = 2 * GSTAGE;             // 128 KiB (the 64 x 260 fp32 slab reuses it)
-using EpiGeo256 = EpiGeo<64, 16, 4, GCS_PITCH>;    // 64 x 256 slab, 1024 threads
+using EpiGeo256 = EpiGeo<64, 16, 4, GCS_PITCH, 64, 1>;    // 64 x 256 slab, 1024 threads (128 registers per lane: one pass at a time in the eavqa_gemm_ln form)
 
 // Order of an XCD's tiles in time (its 32 CUs take them in `local` order): column groups of GN tile columns, inside a group n
 // fastest.  The 32 tiles in flight are then 32 / GN tile rows x GN columns: every A panel is shared by GN concurrent tiles and the
@@ -847,6 +964,7 @@ __device__ __forceinline__ bool big_tile(const GemmParams& p, int gx, int gy, in
     return true;
 }
 
+template <bool LNX>
 __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
@@ -890,6 +1008,8 @@ __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int g
     const int frow = lane & 15, fk = lane >> 4;
     const int arow = wm * 64 + frow, brow = wn * 64 + frow;     // + 16 i ; row & 7 == frow & 7 for every fragment
     issue(0);
+    float2* rowstat = reinterpret_cast<float2*>(smem + GLDS_BYTES);     // eavqa_gemm_ln: under the first tile's round trip
+    if (LNX) ln_rowstat_fill(p, rowstat, m0, n0, GBM, tid, 1024);
     for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0x0070);        // vmcnt(0) lgkmcnt(0): this wave's share of tile kt has landed
@@ -928,7 +1048,7 @@ __global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int g
                     }
         }
         __syncthreads();
-        epilogue<bf16_t, EpiGeo256>(p, Cs, m0 + slab * 64, n0);
+        epilogue<bf16_t, EpiGeo256, LNX>(p, Cs, m0 + slab * 64, n0, LnArgs{rowstat, slab * 64});
         __syncthreads();
     }
 }
@@ -952,15 +1072,20 @@ inline int big_grid(int tiles_m, int tiles_n, int& gx, int& gy) {
 int launch_big(const GemmParams& p, hipStream_t stream) {
     static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
     if (!configured.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                GLDS_BYTES) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GLDS_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_big_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                GLDS_BYTES + LN_ROWSTAT_BYTES) != hipSuccess)
             return EAVQA_E_LAUNCH;
         configured.store(true, std::memory_order_release);
     }
     const int tiles_m = (p.M + GBM - 1) / GBM, tiles_n = (p.N + GBN - 1) / GBN;
     int gx, gy;
     const int per_xcd = big_grid(tiles_m, tiles_n, gx, gy);
-    hipLaunchKernelGGL(gemm_bf16_big_kernel, dim3(per_xcd * 8), dim3(1024), GLDS_BYTES, stream, p, gx, gy, tiles_m, tiles_n);
+    if (p.ln_stats || p.stats_out || p.copy_out)        // eavqa_gemm_ln: its own instantiation (the plain one has no registers to spare)
+        hipLaunchKernelGGL(gemm_bf16_big_kernel<true>, dim3(per_xcd * 8), dim3(1024), GLDS_BYTES + ln_lds(p), stream, p, gx, gy, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL(gemm_bf16_big_kernel<false>, dim3(per_xcd * 8), dim3(1024), GLDS_BYTES, stream, p, gx, gy, tiles_m, tiles_n);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }
@@ -1206,8 +1331,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
                 const int col = wn * 64 + j * 32 + (lane & 31);
                 Cs[row * CS_PITCH + col] = acc[i][j][r];
             }
+    float2* rowstat = reinterpret_cast<float2*>(smem + CS_BYTES);          // present when launched with ln_lds(p) extra bytes
+    ln_rowstat_fill(p, rowstat, m0, n0, BM, tid, 256);
     __syncthreads();
-    epilogue<float>(p, Cs, m0, n0);
+    epilogue_any<float>(p, Cs, m0, n0, LnArgs{rowstat, 0});
 }
 
 typedef void (*gemm_kernel_t)(GemmParams);
@@ -1220,7 +1347,7 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
     for (int i = 0; i < 8; ++i) done |= (configured[i].load(std::memory_order_acquire) == kernel);
     if (!done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                CS_BYTES) != hipSuccess)
+                                CS_BYTES + LN_ROWSTAT_BYTES) != hipSuccess)
             return EAVQA_E_LAUNCH;
         for (int i = 0; i < 8; ++i) {
             gemm_kernel_t expected = nullptr;
@@ -1228,7 +1355,7 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
         }
     }
     const int nwg = p.tiles_m * p.tiles_n;
-    hipLaunchKernelGGL(kernel, dim3(nwg), dim3(256), CS_BYTES, stream, p);
+    hipLaunchKernelGGL(kernel, dim3(nwg), dim3(256), CS_BYTES + ln_lds(p), stream, p);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }
@@ -1236,13 +1363,33 @@ int launch(gemm_kernel_t kernel, const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
-                             const void* A, int64_t lda, const void* B, int64_t ldb,
-                             void* C, int64_t ldc, int out_flags, float alpha,
-                             const float* bias, int act,
-                             const void* aux_in, void* aux_out, int64_t ld_aux,
-                             const void* residual, int64_t ldr, void* stream, int knobs) {
+namespace {
+// rows [r0, ...) of an eavqa_gemm_ln argument block (the second launch of a row-split problem)
+eavqa_gemm_ln_t ln_rows_from(const eavqa_gemm_ln_t& x, int64_t r0, size_t esz) {
+    eavqa_gemm_ln_t y = x;
+    if (x.copy_out) y.copy_out = static_cast<char*>(x.copy_out) + (size_t)r0 * (size_t)x.ld_copy * esz;
+    if (x.stats_out) y.stats_out = x.stats_out + (size_t)r0 * (size_t)x.stats_ld * 2;
+    if (x.ln_stats) y.ln_stats = x.ln_stats + (size_t)r0 * (size_t)x.ln_ld * 2;
+    if (x.mean_out) y.mean_out = x.mean_out + r0;
+    if (x.rstd_out) y.rstd_out = x.rstd_out + r0;
+    return y;
+}
+
+int gemm_impl(int dtype, int a_kc, int b_kc, int M, int N, int K,
+              const void* A, int64_t lda, const void* B, int64_t ldb,
+              void* C, int64_t ldc, int out_flags, float alpha,
+              const float* bias, int act,
+              const void* aux_in, void* aux_out, int64_t ld_aux,
+              const void* residual, int64_t ldr, const eavqa_gemm_ln_t* ln, void* stream, int knobs) {
     const Knobs kn(knobs);
+    const bool ln_consumer = ln && ln->ln_stats;
+    if (ln) {
+        if (ln->copy_out && ln->ld_copy < N) return EAVQA_E_ARG;
+        if (ln->stats_out && ln->stats_ld < (N + 63) / 64) return EAVQA_E_ARG;
+        if (ln_consumer && (!ln->ln_c || ln->ln_parts <= 0 || ln->ln_ld < ln->ln_parts || ln->ln_cols <= 0 || !(ln->ln_eps >= 0.f))) return EAVQA_E_ARG;
+        if ((ln->mean_out != nullptr) != (ln->rstd_out != nullptr) || (ln->mean_out && !ln_consumer)) return EAVQA_E_ARG;
+        if (ln_consumer && !(a_kc && b_kc)) return EAVQA_E_SHAPE;
+    }
     if (out_flags & ~(EAVQA_GEMM_OUT_F32 | EAVQA_GEMM_RESIDUAL_LOWP | EAVQA_GEMM_STREAM_F16)) return EAVQA_E_ARG;
     if ((out_flags & (EAVQA_GEMM_RESIDUAL_LOWP | EAVQA_GEMM_STREAM_F16)) && dtype != EAVQA_BF16) return EAVQA_E_DTYPE;   // 16-bit streams: bf16 operands only
     const int out_f32 = out_flags & EAVQA_GEMM_OUT_F32;
@@ -1277,6 +1424,14 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     p.vec_aux = vec_ok(aux_in ? aux_in : aux_out, ld_aux, esz);
     p.vec_res = vec_ok(residual, ldr, res_lowp ? esz : 4);
     p.vec_bias = (reinterpret_cast<uintptr_t>(bias) % 16) == 0;
+    if (ln) {
+        p.copy_out = ln->copy_out; p.ld_copy = ln->ld_copy; p.vec_copy = ln->copy_out ? vec_ok(ln->copy_out, ln->ld_copy, esz) : 0;
+        p.stats_out = ln->stats_out; p.stats_ld = ln->stats_ld;
+        if (ln_consumer) {
+            p.ln_stats = ln->ln_stats; p.ln_parts = ln->ln_parts; p.ln_ld = ln->ln_ld; p.ln_c = ln->ln_c;
+            p.ln_inv_n = 1.0f / float(ln->ln_cols); p.ln_eps = ln->ln_eps; p.mean_out = ln->mean_out; p.rstd_out = ln->rstd_out;
+        }
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EAVQA_BF16) {
         if (a_kc && b_kc && (K % 64) == 0 && kn.k64_mode >= 2 && kn.k64_mode < 2 + N_K64) return K64_SHAPES[kn.k64_mode - 2].launch(p, s);
@@ -1284,7 +1439,7 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
         // weight-streaming kernel has N / 16 workgroups - 8.7 against 15.1 us at N = K = 2048, 20.9 against 31.9 us at K = 5120 (cold
         // weights); from N = 6144 on the tiles win again (16.6 against 22.3 us at N = 10240)
         const bool few_columns = kn.k64_mode == 0 && kn.shape_mode == 0 && kn.big_mode == 0 && N <= 4096;
-        if (a_kc && b_kc && !kn.disable_fast && M <= 64 && (K % 32) == 0 && N >= 64 && (kn.k64_mode == 1 || (K % 64) != 0 || few_columns)) return launch_skinny(p, s);
+        if (!ln && a_kc && b_kc && !kn.disable_fast && M <= 64 && (K % 32) == 0 && N >= 64 && (kn.k64_mode == 1 || (K % 64) != 0 || few_columns)) return launch_skinny(p, s);
         // Default dispatch (K % 64 == 0): the loader / consumer specialised full-line tile the cost model ranks first, or the
         // round-1 256 x 256 kernel where the model says its 1/128 B-per-FLOP intensity wins (problems with hundreds of such tiles:
         // the CLIP tower, few-shot prefill, lm_head forward).  M <= 64 weight-streaming shapes take the same route.
@@ -1308,9 +1463,11 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
             auto off = [](const void* base, int64_t rows, int64_t ld, size_t es) -> const void* {
                 return base ? static_cast<const char*>(base) + (size_t)rows * (size_t)ld * es : nullptr;
             };
-            return eavqa_gemm_ex(dtype, a_kc, b_kc, big_rem, N, K, off(A, r0, lda, 2), lda, B, ldb, const_cast<void*>(off(C, r0, ldc, ces)), ldc, out_flags,
-                                 alpha, bias, act, off(aux_in, r0, ld_aux, 2), const_cast<void*>(off(aux_out, r0, ld_aux, 2)), ld_aux,
-                                 off(residual, r0, ldr, res_es), ldr, stream, 0);
+            eavqa_gemm_ln_t ln2;
+            if (ln) ln2 = ln_rows_from(*ln, r0, 2);
+            return gemm_impl(dtype, a_kc, b_kc, big_rem, N, K, off(A, r0, lda, 2), lda, B, ldb, const_cast<void*>(off(C, r0, ldc, ces)), ldc, out_flags,
+                             alpha, bias, act, off(aux_in, r0, ld_aux, 2), const_cast<void*>(off(aux_out, r0, ld_aux, 2)), ld_aux,
+                             off(residual, r0, ldr, res_es), ldr, ln ? &ln2 : nullptr, stream, 0);
         };
         int bgx, bgy;
         const int big_rounds = (big_grid((M - big_rem + GBM - 1) / GBM, (N + GBN - 1) / GBN, bgx, bgy) + 31) / 32;      // the rounds launch_big runs
@@ -1336,7 +1493,7 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
             if (M > 64 && big_cost < best) return run_big(p);
             return K64_SHAPES[pick].launch(p, s);
         }
-        if (a_kc && b_kc && !kn.disable_fast && (K % FBK) == 0) {
+        if (a_kc && b_kc && !kn.disable_fast && (K % FBK) == 0 && !ln_consumer) {      // (those kernels carry no row statistics: the general kernel below does)
             if (kn.shape_mode >= 2 && kn.shape_mode < 7) return SHAPES[kn.shape_mode - 2].launch(p, s);
             const bool big_ok = (K % GBK) == 0 && kn.big_mode != 1;
             if (big_ok && kn.big_mode == 2) return run_big(p);
@@ -1367,6 +1524,38 @@ extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
     if (a_kc && !b_kc) return launch(gemm_f32_kernel<true, false>, p, s);
     if (!a_kc && b_kc) return launch(gemm_f32_kernel<false, true>, p, s);
     return launch(gemm_f32_kernel<false, false>, p, s);
+}
+}  // namespace
+
+extern "C" int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
+                             const void* A, int64_t lda, const void* B, int64_t ldb,
+                             void* C, int64_t ldc, int out_flags, float alpha,
+                             const float* bias, int act,
+                             const void* aux_in, void* aux_out, int64_t ld_aux,
+                             const void* residual, int64_t ldr, void* stream, int knobs) {
+    return gemm_impl(dtype, a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, out_flags, alpha, bias, act, aux_in, aux_out, ld_aux, residual, ldr,
+                     nullptr, stream, knobs);
+}
+
+extern "C" int eavqa_gemm_ln_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
+                                const void* A, int64_t lda, const void* B, int64_t ldb,
+                                void* C, int64_t ldc, int out_flags, float alpha,
+                                const float* bias, int act,
+                                const void* aux_in, void* aux_out, int64_t ld_aux,
+                                const void* residual, int64_t ldr, const eavqa_gemm_ln_t* ln, void* stream, int knobs) {
+    if (!ln) return EAVQA_E_ARG;
+    return gemm_impl(dtype, a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, out_flags, alpha, bias, act, aux_in, aux_out, ld_aux, residual, ldr,
+                     ln, stream, knobs);
+}
+
+extern "C" int eavqa_gemm_ln(int dtype, int a_kc, int b_kc, int M, int N, int K,
+                             const void* A, int64_t lda, const void* B, int64_t ldb,
+                             void* C, int64_t ldc, int out_flags, float alpha,
+                             const float* bias, int act,
+                             const void* aux_in, void* aux_out, int64_t ld_aux,
+                             const void* residual, int64_t ldr, const eavqa_gemm_ln_t* ln, void* stream) {
+    return eavqa_gemm_ln_ex(dtype, a_kc, b_kc, M, N, K, A, lda, B, ldb, C, ldc, out_flags, alpha, bias, act, aux_in, aux_out, ld_aux, residual,
+                            ldr, ln, stream, 0);
 }
 
 extern "C" int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,

@@ -112,8 +112,9 @@ __device__ __forceinline__ void k64s_loader_role(const char* A, const char* B, i
 }
 
 // C tile of the consumer waves -> LDS (the ring) -> shared epilogue, in passes; ALL waves of the workgroup take part.
-template <class G, int WM, int WN, int MF, int NF>
-__device__ __forceinline__ void k64s_store_tile(const GemmParams& p, const f32x4 (&acc)[MF][NF], char* smem, int wave, int lane, int m0, int n0) {
+template <class G, int WM, int WN, int MF, int NF, bool LNX = false>
+__device__ __forceinline__ void k64s_store_tile(const GemmParams& p, const f32x4 (&acc)[MF][NF], char* smem, int wave, int lane, int m0, int n0,
+                                                const float2* rowstat = nullptr) {
     const int wm = wave / WN, wn = wave % WN;
     float* Cs = reinterpret_cast<float*>(smem);
     constexpr int CH = MF / G::MFC;
@@ -136,12 +137,14 @@ __device__ __forceinline__ void k64s_store_tile(const GemmParams& p, const f32x4
             }
         }
         __syncthreads();
-        epilogue<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>>(p, Cs, m0 + wgrp * G::SP * 16 * MF + chunk * 16 * G::MFC, n0);
+        const int row_base = wgrp * G::SP * 16 * MF + chunk * 16 * G::MFC;
+        epilogue<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>, LNX>(p, Cs, m0 + row_base, n0, LnArgs{rowstat, row_base});
         if (pass + 1 < NPASSES) __syncthreads();
     }
 }
 
-template <int WM, int WN, int MF, int NF, int NST, int LW>
+// LNX: the eavqa_gemm_ln form (its own instantiation: the plain kernels stay what they were, instruction for instruction)
+template <int WM, int WN, int MF, int NF, int NST, int LW, bool LNX>
 __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
     using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(Gem
 #pragma unroll
         for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int wm = wave / WN, wn = wave % WN;                               // meaningful for consumers (wave < NC)
+    float2* rowstat = reinterpret_cast<float2*>(smem + G::RING);            // present when launched with ln_lds(p) extra bytes
 
     if (wave >= G::NC) {
         k64s_loader_role<G>(reinterpret_cast<const char*>(p.A), reinterpret_cast<const char*>(p.B), p.lda * 2, p.ldb * 2, p.M, p.N, m0, n0, nk,
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(Gem
                 for (int j = 0; j < NF; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
         };
+        if (LNX) ln_rowstat_fill(p, rowstat, m0, n0, G::TBM, tid, 64 * G::NC);   // eavqa_gemm_ln: under the first tile's round trip
         __builtin_amdgcn_s_barrier();
         read_frags(0, smem, sw0);
         int stage = 0;
@@ -209,7 +214,7 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(Gem
         if (acc[0][0][0] == 12345.678f) reinterpret_cast<float*>(p.C)[0] = acc[0][0][0];
         return;
     }
-    k64s_store_tile<G, WM, WN, MF, NF>(p, acc, smem, wave, lane, m0, n0);
+    k64s_store_tile<G, WM, WN, MF, NF, LNX>(p, acc, smem, wave, lane, m0, n0, rowstat);
 }
 
 template <int WM, int WN, int MF, int NF, int NST, int LW>
@@ -217,15 +222,22 @@ int launch_k64s(const GemmParams& p, hipStream_t stream) {
     using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
     static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
     if (!configured.load(std::memory_order_acquire)) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::RING + LN_ROWSTAT_BYTES) != hipSuccess)
             return EAVQA_E_LAUNCH;
         configured.store(true, std::memory_order_release);
     }
+    static_assert(G::RING + LN_ROWSTAT_BYTES <= 160 * 1024, "ring + row statistics of eavqa_gemm_ln");
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
-    hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
-                       tiles_m, tiles_n);
+    if (p.ln_stats || p.stats_out || p.copy_out)
+        hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, true>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING + ln_lds(p), stream, p,
+                           g.gx, g.gy, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, false>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
+                           tiles_m, tiles_n);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }

@@ -186,7 +186,8 @@ def linear(a: Tensor, w, **kw) -> Tensor:
 
 class _Layer:
     __slots__ = ("ln1_g", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_g", "ln2_b", "w_fc1", "b_fc1", "w_fc2", "b_fc2",
-                 "w_qkv_t", "w_o_t", "w_fc1_t", "w_fc2_t")
+                 "w_qkv_t", "w_o_t", "w_fc1_t", "w_fc2_t",
+                 "w_qkv_f", "c_qkv", "d_qkv", "w_fc1_f", "c_fc1", "d_fc1")      # LayerNorm folded into the consuming Linear (_prepare_fold)
 
 
 class FrozenCausalLM:
@@ -207,6 +208,11 @@ class FrozenCausalLM:
         self.weight_format = weight_format
         self._pack(state_dict)
         self._bwd_ready = False
+        # eavqa_gemm_ln: ln_1 / ln_2 of layers 1.. (and ln_2 of layer 0) as an epilogue term of the QKV / FFN-up products instead of a
+        # kernel of their own - bf16 weights only.  Measured equal to the LayerNorm kernels on cfg2 (what the 72 removed launches save, the
+        # four longer GEMM epilogues per layer cost: profiles/round4_ln_fold.md), so it is an option (EAVQA_LN_FOLD=1), not the default.
+        self.fold_layernorm = (dtype == torch.bfloat16 and weight_format == "native" and os.environ.get("EAVQA_LN_FOLD", "0") == "1")
+        self._fold_ready = False
 
     # ---------------------------------------------------------------- packing
     def _T(self, t: Tensor) -> Tensor:
@@ -292,6 +298,22 @@ class FrozenCausalLM:
             self.head_t[:, :V] = self.head.T
         self._bwd_ready = True
 
+    def _prepare_fold(self) -> None:
+        """``LayerNorm(x) W^T + b = rstd (x W'^T - mean c) + d`` with ``W' = W * gamma``, ``c = W' 1``, ``d = W beta + b`` (include/eavqa.h,
+        eavqa_gemm_ln): the folded copies of the two weights of every layer that follow a LayerNorm, made once on the first training /
+        scoring forward.  ``c`` sums W' AS STORED (bf16), so the rank-1 term cancels the mean of exactly the product the kernel forms."""
+        if self._fold_ready:
+            return
+        for L in self.layers:
+            for w, b, g, be, nm in ((L.w_qkv, L.b_qkv, L.ln1_g, L.ln1_b, "qkv"), (L.w_fc1, L.b_fc1, L.ln2_g, L.ln2_b, "fc1")):
+                w32 = w.float()
+                wf = (w32 * g[None, :]).to(self.dtype).contiguous()
+                setattr(L, f"w_{nm}_f", wf)
+                setattr(L, f"c_{nm}", wf.float().sum(1).contiguous())
+                setattr(L, f"d_{nm}", (w32 @ be + b).contiguous())
+                del w32
+        self._fold_ready = True
+
     def resize_token_embeddings(self, n: int) -> None:
         """``model.gpt.resize_token_embeddings(len(tokenizer))`` src/trainers/clipcap_exector.py:56.
         New rows get the mean of the existing embeddings (HF draws them around that mean)."""
@@ -364,27 +386,53 @@ class FrozenCausalLM:
             attn_mask = mask
         x = ops.embed_assemble(src, pos, self.wte, prefix_rows, self.wpe)
         tape = [] if save else None
-        for L in self.layers:
-            if save:
-                a, mean1, rstd1 = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T, save_stats=True)
+        fold = self.fold_layernorm and M > 64
+        if fold:
+            self._prepare_fold()
+        n_slots = (E + 63) // 64
+        f32 = dict(device=self.device, dtype=torch.float32)
+        xT = st = None                                      # with `fold`: the stream in the compute dtype and its row sums (from layer 0's FFN-down on)
+        for li, L in enumerate(self.layers):
+            if st is not None:                              # ln_1 folded into the QKV projection
+                mean1, rstd1 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
+                qkv = ops.gemm(xT, L.w_qkv_f, bias=L.d_qkv, ln_stats=st, ln_c=L.c_qkv, ln_eps=c.eps, ln_save=(mean1, rstd1) if save else None)
             else:
-                a = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T)
-            qkv = linear(a, L.w_qkv, bias=L.b_qkv)
+                if save:
+                    a, mean1, rstd1 = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T, save_stats=True)
+                else:
+                    a = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T)
+                qkv = linear(a, L.w_qkv, bias=L.b_qkv)
             q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
             if save:
                 ctx, lse = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=attn_mask, causal=True, scale=scale,
                                              save_lse=True, cu_seqlens=cu)
             else:
                 ctx = ops.attention_fwd(q, k, v, B, H, S, S, hd, key_mask=attn_mask, causal=True, scale=scale, cu_seqlens=cu)
-            x1 = linear(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True)
-            if save:
-                a2, mean2, rstd2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T, save_stats=True)
-                u = torch.empty((M, c.ffn), device=self.device, dtype=T)
-                f = linear(a2, L.w_fc1, bias=L.b_fc1, act=c.act, aux_out=u)
+            if fold:
+                # the out-projection leaves the stream a second time in the compute dtype + its row sums; ln_2 is a term of FFN-up's epilogue
+                x1T = torch.empty((M, E), device=self.device, dtype=T)
+                st1 = torch.empty((M, n_slots, 2), **f32)
+                x1 = ops.gemm(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True, copy_out=x1T, stats_out=st1)
+                mean2, rstd2 = (torch.empty(M, **f32), torch.empty(M, **f32)) if save else (None, None)
+                u = torch.empty((M, c.ffn), device=self.device, dtype=T) if save else None
+                f = ops.gemm(x1T, L.w_fc1_f, bias=L.d_fc1, act=c.act, aux_out=u, ln_stats=st1, ln_c=L.c_fc1, ln_eps=c.eps,
+                             ln_save=(mean2, rstd2) if save else None)
+                if li + 1 < len(self.layers):
+                    xT = torch.empty((M, E), device=self.device, dtype=T)
+                    st = torch.empty((M, n_slots, 2), **f32)
+                    x2 = ops.gemm(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True, copy_out=xT, stats_out=st)
+                else:
+                    x2 = ops.gemm(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True)
             else:
-                a2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T)
-                f = linear(a2, L.w_fc1, bias=L.b_fc1, act=c.act)
-            x2 = linear(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True)
+                x1 = linear(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True)
+                if save:
+                    a2, mean2, rstd2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T, save_stats=True)
+                    u = torch.empty((M, c.ffn), device=self.device, dtype=T)
+                    f = linear(a2, L.w_fc1, bias=L.b_fc1, act=c.act, aux_out=u)
+                else:
+                    a2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T)
+                    f = linear(a2, L.w_fc1, bias=L.b_fc1, act=c.act)
+                x2 = linear(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True)
             if save:
                 tape.append((x, mean1, rstd1, qkv, ctx, lse, x1, mean2, rstd2, u))
             x = x2

@@ -5,7 +5,8 @@ is one of the calls below.  Nothing here computes with torch ops on the data pat
 """
 from __future__ import annotations
 
-from typing import Optional
+import ctypes as C
+from typing import Optional, Tuple
 
 import torch
 
@@ -62,9 +63,14 @@ def _ld(t: Tensor) -> int:
 def gemm(a: Tensor, b: Tensor, *, a_kc: bool = True, b_kc: bool = True, bias: Optional[Tensor] = None,
          act: str = "none", aux_in: Optional[Tensor] = None, aux_out: Optional[Tensor] = None,
          residual: Optional[Tensor] = None, out: Optional[Tensor] = None, out_f32: bool = False,
-         alpha: float = 1.0) -> Tensor:
+         alpha: float = 1.0, copy_out: Optional[Tensor] = None, stats_out: Optional[Tensor] = None, ln_stats: Optional[Tensor] = None,
+         ln_c: Optional[Tensor] = None, ln_eps: float = 1e-5, ln_save: Optional[Tuple[Tensor, Tensor]] = None) -> Tensor:
     """``C = epilogue(alpha * A @ B^T)`` - see eavqa_gemm.  ``a``: [M,K] (a_kc) or [K,M];
-    ``b``: [N,K] (b_kc, nn.Linear layout) or [K,N] (Conv1D layout)."""
+    ``b``: [N,K] (b_kc, nn.Linear layout) or [K,N] (Conv1D layout).
+
+    eavqa_gemm_ln (a frozen pre-LN layer's LayerNorm folded into its neighbours), producer side: ``copy_out`` [M, N] in the operand
+    dtype, ``stats_out`` float32 [M, >= ceil(N / 64), 2]; consumer side: ``ln_stats`` (a producer's ``stats_out`` for the rows of
+    ``a``), ``ln_c`` float32 [N], ``ln_eps``, ``ln_save`` = (mean, rstd) float32 [M] to be written."""
     _dev(a)
     M, K = (a.shape if a_kc else (a.shape[1], a.shape[0]))
     N, Kb = (b.shape if b_kc else (b.shape[1], b.shape[0]))
@@ -93,7 +99,30 @@ def gemm(a: Tensor, b: Tensor, *, a_kc: bool = True, b_kc: bool = True, bias: Op
     args = (dt, int(a_kc), int(b_kc), M, N, K, _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out),
             flags, float(alpha), _p(bias), ACT[act], _p(aux_in), _p(aux_out), _ld(aux) if aux is not None else 0,
             _p(residual), _ld(residual) if residual is not None else 0, _stream())
-    if KernelSelect.gemm:
+    if copy_out is not None or stats_out is not None or ln_stats is not None:
+        g = _lib.GemmLn()
+        if copy_out is not None:
+            if copy_out.dtype != a.dtype or tuple(copy_out.shape) != (M, N):
+                raise _lib.EavqaError("gemm copy_out must be [M, N] in the operand dtype")
+            g.copy_out, g.ld_copy = _p(copy_out), _ld(copy_out)
+        if stats_out is not None:
+            if stats_out.dtype != torch.float32 or stats_out.dim() != 3 or stats_out.shape[0] != M or stats_out.shape[2] != 2 or not stats_out.is_contiguous():
+                raise _lib.EavqaError("gemm stats_out must be a contiguous float32 [M, slots, 2]")
+            g.stats_out, g.stats_ld = _p(stats_out), stats_out.shape[1]
+        if ln_stats is not None:
+            if ln_stats.dtype != torch.float32 or ln_stats.dim() != 3 or ln_stats.shape[0] != M or ln_stats.shape[2] != 2 or not ln_stats.is_contiguous():
+                raise _lib.EavqaError("gemm ln_stats must be a contiguous float32 [M, slots, 2]")
+            if ln_c is None or ln_c.dtype != torch.float32 or ln_c.numel() != N:
+                raise _lib.EavqaError("gemm ln_c must be float32 [N]")
+            g.ln_stats, g.ln_parts, g.ln_ld, g.ln_cols = _p(ln_stats), ln_stats.shape[1], ln_stats.shape[1], K
+            g.ln_c, g.ln_eps = _p(ln_c), float(ln_eps)
+            if ln_save is not None:
+                g.mean_out, g.rstd_out = _p(ln_save[0]), _p(ln_save[1])
+        if KernelSelect.gemm:
+            call("eavqa_gemm_ln_ex", *args[:-1], C.byref(g), args[-1], KernelSelect.gemm)
+        else:
+            call("eavqa_gemm_ln", *args[:-1], C.byref(g), args[-1])
+    elif KernelSelect.gemm:
         call("eavqa_gemm_ex", *args, KernelSelect.gemm)
     else:
         call("eavqa_gemm", *args)

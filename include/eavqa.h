@@ -89,6 +89,38 @@ int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
                const void* aux_in, void* aux_out, int64_t ld_aux,
                const void* residual, int64_t ldr, void* stream);
 
+/* eavqa_gemm with the LayerNorm between two Linear layers of a FROZEN pre-LN decoder layer folded into its neighbours (round 4; HF
+ * modeling_gpt2.py:246-309 `ln_1 -> c_attn`, `ln_2 -> c_fc`; modeling_opt.py:184-254 `self_attn_layer_norm -> q/k/v_proj`,
+ * `final_layer_norm -> fc1`).  With W' = W * gamma (column-wise), c[n] = sum_k W'(n,k) and d = W beta + bias, prepared once at load:
+ *     LayerNorm(x) W^T + bias  =  rstd (x W'^T - mean c) + d
+ * so the normalisation is a per-row scale and a rank-1 term of the consuming product's epilogue, and no LayerNorm kernel runs:
+ *   producer (the Linear whose result is the stream x: out-projection, FFN-down):
+ *     copy_out  != NULL: the result a second time in `dtype`, leading dimension ld_copy (the consumer's A operand);
+ *     stats_out != NULL: float32 [M, stats_ld, 2], stats_ld >= ceil(N / 64): (sum, sum of squares) of every result row (of the values as
+ *                        stored in C before any rounding) spread over 64-column slots - a tile writes its whole sum into its first slot and
+ *                        zeros into the others, so the consumer adds all stats_ld slots whatever tile width produced them;
+ *   consumer (QKV projection, FFN-up), a_kc and b_kc forms only:
+ *     ln_stats != NULL: the producer's stats (leading dimension ln_ld slots, ln_parts of them summed), ln_cols = the length of a stream
+ *                       row; A = the UN-normalised rows in `dtype`, B = W', bias = d, ln_c = c (float32 [N]):
+ *                       v = rstd[m] (alpha acc - mean[m] c[n]) + bias[n], then the rest of eavqa_gemm's epilogue;
+ *                       mean = sum / ln_cols, rstd = 1 / sqrt(sumsq / ln_cols - mean^2 + ln_eps);
+ *     mean_out / rstd_out (both or neither): float32 [M], what eavqa_layernorm_fwd would have saved for eavqa_layernorm_bwd.
+ * Either side may be used alone; every pointer of `ln` may be NULL.  Not available with the M <= 64 weight-streaming kernel (the call
+ * takes a tiled kernel instead). */
+typedef struct {
+    void* copy_out; int64_t ld_copy;
+    float* stats_out; int32_t stats_ld;
+    const float* ln_stats; int32_t ln_parts; int32_t ln_ld; int32_t ln_cols;
+    const float* ln_c; float ln_eps;
+    float* mean_out; float* rstd_out;
+} eavqa_gemm_ln_t;
+int eavqa_gemm_ln(int dtype, int a_kc, int b_kc, int M, int N, int K,
+                  const void* A, int64_t lda, const void* B, int64_t ldb,
+                  void* C, int64_t ldc, int out_flags, float alpha,
+                  const float* bias, int act,
+                  const void* aux_in, void* aux_out, int64_t ld_aux,
+                  const void* residual, int64_t ldr, const eavqa_gemm_ln_t* ln, void* stream);
+
 /* ----------------------------------------------------------- LayerNorm ---
  * torch.nn.LayerNorm over the last dim (ln_1/ln_2/ln_f HF:gpt2 :253-257,620;
  * self_attn_layer_norm/final_layer_norm HF:opt :196-205; CLIP layer_norm1/2, pre/post

@@ -34,6 +34,13 @@ int eavqa_gemm_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
                   const float* bias, int act,
                   const void* aux_in, void* aux_out, int64_t ld_aux,
                   const void* residual, int64_t ldr, void* stream, int knobs);
+/* eavqa_gemm_ln with the same knobs (every kernel family carries the folded-LayerNorm epilogue; the tests force each) */
+int eavqa_gemm_ln_ex(int dtype, int a_kc, int b_kc, int M, int N, int K,
+                     const void* A, int64_t lda, const void* B, int64_t ldb,
+                     void* C, int64_t ldc, int out_flags, float alpha,
+                     const float* bias, int act,
+                     const void* aux_in, void* aux_out, int64_t ld_aux,
+                     const void* residual, int64_t ldr, const eavqa_gemm_ln_t* ln, void* stream, int knobs);
 
 /* eavqa_attention_fwd / _bwd with a path selector: bit 0 keeps bf16 on the vector-ALU kernels (instead of the matrix-core
  * ones), bit 1 (backward) takes the dQ + dK/dV kernel pair even when the problem is one tile, bit 2 (forward) keeps the

@@ -31,7 +31,7 @@ def test_header_declares_the_expected_surface():
     public = declared_symbols(("eavqa.h",))
     # the drop-in boundary carries no test hooks and no process-global switches
     assert not [n for n in public if "debug" in n or n.endswith("_ex")]
-    assert set(declared_symbols(("eavqa_test.h",))) - set(public) == {"eavqa_gemm_ex", "eavqa_attention_fwd_ex", "eavqa_attention_bwd_ex",
+    assert set(declared_symbols(("eavqa_test.h",))) - set(public) == {"eavqa_gemm_ex", "eavqa_gemm_ln_ex", "eavqa_attention_fwd_ex", "eavqa_attention_bwd_ex",
                                                                                 "eavqa_gemm_splitk_ex", "eavqa_lm_block_forward_ex",
                                                                                 "eavqa_gemm_decode_ex", "eavqa_t5_decoder_step_ex"}
 

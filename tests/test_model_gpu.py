@@ -465,3 +465,48 @@ def test_pipelined_adamw_is_bit_equal_and_the_forward_waits_per_layer(mapping_ty
         torch.cuda.synchronize()
         finals.append((fl.master.clone(), fl.shadow.clone(), float(out.loss.item())))
     assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1]) and finals[0][2] == finals[1][2]
+
+
+@pytest.mark.parametrize("arch", ["gpt2", "opt"])
+@pytest.mark.parametrize("pack", [False, True])
+def test_folded_layernorm_training_step_matches_the_layernorm_kernels_bf16(arch, pack):
+    """``FrozenCausalLM.fold_layernorm`` (eavqa_gemm_ln: ln_1 / ln_2 as an epilogue term of the QKV / FFN-up products, the stream's row
+    sums and bf16 copy written by the out-projection / FFN-down epilogues) against the same bf16 model with the LayerNorm kernels, and
+    both against the fp32 oracle: the folded step must sit as close to the oracle as the unfolded one (the two differ from each other by
+    bf16 roundings taken at different places: of x instead of LayerNorm(x), of W gamma instead of W)."""
+    from eavqa_amd.models.clipcap import ClipCaptionPrefix
+    from eavqa_amd.models.lm import FrozenCausalLM
+    cfg, sd = _tiny_lm(V=320, E=128, n_layer=4, n_head=4, arch=arch)
+    L, D, B, Tt = 4, 24, 9, 20                                     # 216 rows padded, ~170 packed: above the 64-row limit of the fold
+    g = torch.Generator().manual_seed(11)
+    pad = cfg.vocab - 1
+    lens = torch.randint(8, Tt + 1, (B,), generator=g)
+    ids = torch.randint(2, cfg.vocab - 2, (B, Tt), generator=g)
+    mask = (torch.arange(Tt)[None] < lens[:, None]).long()
+    ids = ids * mask + pad * (1 - mask)
+    labels = oracle.label_mask_cc(ids, pad)
+    prefix = torch.randn(B, D, generator=g)
+    res = {}
+    for fold in (False, True):
+        lm = FrozenCausalLM(cfg, sd, torch.bfloat16, DEV)
+        assert not lm.fold_layernorm                               # an option (EAVQA_LN_FOLD=1), measured equal: off by default
+        lm.fold_layernorm = fold
+        torch.manual_seed(1)
+        model = ClipCaptionPrefix(prefix_length=L, prefix_size=D, mapping_type="mlp", lm=lm, dtype=torch.bfloat16, device=DEV).train()
+        model.pack_padding = pack
+        out = model(question_tokens=ids, prefix=prefix, question_mask=mask, labels=labels)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res[fold] = (out.loss.item(), out.logits.float().cpu(), {k: p.grad.float().cpu().clone() for k, p in model.clip_project.named_parameters()})
+        mapper = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in model.clip_project.state_dict().items()}
+    ocfg = dict(arch=arch, n_layer=cfg.n_layer, n_head=cfg.n_head, act=cfg.act)
+    loss, logits = oracle.clipcap_forward(sd, ocfg, mapper, dict(prefix_length=L, mapping_type="mlp"), ids, prefix, mask, labels)
+    loss.backward()
+    attended = torch.cat([torch.ones(B, L, dtype=torch.bool), mask.bool()], dim=1)
+    err = {f: (res[f][1][attended] - logits.detach()[attended]).abs().max().item() for f in res}
+    assert err[True] <= max(1.5 * err[False], 2e-2), err
+    assert abs(res[True][0] - loss.item()) <= max(1.5 * abs(res[False][0] - loss.item()), 3e-3)
+    for k in res[True][2]:
+        want = mapper[k].grad
+        e = {f: (res[f][2][k] - want).abs().max().item() for f in res}
+        assert e[True] <= max(1.5 * e[False], 2e-2 * want.abs().max().item()), (k, e)
