@@ -26,6 +26,8 @@ SIGNATURES = {
     "eavqa_gemm": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i32, f32, ptr, i32, ptr, ptr, i64, ptr, i64, ptr],
     "eavqa_layernorm_fwd": [i32, i32, i32, i32, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, ptr, ptr],
     "eavqa_layernorm_bwd": [i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, ptr, ptr, i64, ptr],
+    "eavqa_layernorm_fwd_fp8": [i32, i32, i32, ptr, i64, ptr, ptr, f32, ptr, i64, ptr, ptr, ptr, ptr],
+    "eavqa_layernorm_bwd_fp8": [i32, i32, i32, ptr, i64, ptr, i64, ptr, ptr, ptr, ptr, ptr, i64, ptr, i64, ptr, ptr],
     "eavqa_attention_fwd": [i32, i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, ptr, i64, i64, i64, ptr, i64, ptr, i32, f32, ptr, ptr],
     "eavqa_attention_decode": [i32, i32, i32, i32, i32, ptr, i64, ptr, i64, ptr, i64, i64, ptr, ptr, i64, ptr, i64, ptr, i64, f32, ptr],
     "eavqa_attention_decode_splitk": [i32, i32, i32, i32, i32, ptr, i32, ptr, ptr, i64, ptr, i64, i64, ptr, i64, ptr, i64, f32, ptr],

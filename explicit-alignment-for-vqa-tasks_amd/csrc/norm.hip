@@ -18,10 +18,39 @@ __device__ __forceinline__ float4 ldrow4(const void* base, int64_t off, int kind
     return elem<T>::ld4(reinterpret_cast<const T*>(base) + off);
 }
 
+template <typename T> __device__ __forceinline__ float4 round_to(const float4 o) {
+    return make_float4((float)(T)o.x, (float)(T)o.y, (float)(T)o.z, (float)(T)o.w);
+}
+
+// The row-wise e4m3 quantisation of eavqa_quantize_rows_fp8 on a row that one wave holds in registers (lane l: float4 l, l + 64, ...;
+// entries beyond nv are zeros): scale = amax / 448 (1 for an all-zero row), q = cvt(v / scale) - the same arithmetic, so the bytes and the
+// scale are those of the separate kernel.  (eavqa_layernorm_fwd_fp8 / _bwd_fp8: the quantiser fused into its row-complete producers.)
+template <int NV>
+__device__ __forceinline__ void quantize_row_e4m3(const float4 (&v)[NV], int nv, int lane, unsigned char* q, float* scale_out) {
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < nv) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+    amax = wave_max(amax);
+    const float scale = amax > 0.f ? amax * (1.f / 448.f) : 1.f;
+    const float inv = 1.f / scale;
+    if (lane == 0) *scale_out = scale;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].x * inv, v[i].y * inv, 0, false);
+            pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[i].z * inv, v[i].w * inv, pk, true);
+            *reinterpret_cast<int*>(q + 4 * c) = pk;
+        }
+    }
+}
+
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(int x_f32, int rows, int cols, const void* x, int64_t ldx,
                                                      const float* gamma, const float* beta, float eps,
-                                                     T* y, int64_t ldy, float* mean, float* rstd) {
+                                                     T* y, int64_t ldy, float* mean, float* rstd,
+                                                     unsigned char* yq = nullptr, int64_t ldq = 0, float* yq_scale = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -66,9 +95,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(int x_f32, int rows, int co
             o.y = (v[i].y - mu) * rs * gm[i].y + bt[i].y;
             o.z = (v[i].z - mu) * rs * gm[i].z + bt[i].z;
             o.w = (v[i].w - mu) * rs * gm[i].w + bt[i].w;
-            elem<T>::st4(y + (int64_t)row * ldy + 4 * c, o);
+            if (y) elem<T>::st4(y + (int64_t)row * ldy + 4 * c, o);
+            if (yq) v[i] = round_to<T>(o);            // what eavqa_quantize_rows_fp8 would read back: the values in the storage type
         }
     }
+    if (yq) quantize_row_e4m3<NV>(v, nv, lane, yq + (int64_t)row * ldq, yq_scale + row);
 }
 
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
@@ -77,7 +108,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int x_f32, int rows, int co
                                                      const T* dy, int64_t lddy, const float* gamma,
                                                      const float* mean, const float* rstd, const float* dres,
                                                      float* dx, int64_t lddx, float* dgamma, float* dbeta,
-                                                     T* dx_lowp, int64_t ld_lowp) {
+                                                     T* dx_lowp, int64_t ld_lowp,
+                                                     unsigned char* dxq = nullptr, int64_t ldq = 0, float* dxq_scale = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -116,8 +148,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(int x_f32, int rows, int co
             o.w = r.w + rs * (gd[i].w - m1 - xh[i].w * m2);
             *reinterpret_cast<float4*>(dx + (int64_t)row * lddx + 4 * c) = o;
             if (dx_lowp) elem<T>::st4(dx_lowp + (int64_t)row * ld_lowp + 4 * c, o);
+            if (dxq) gd[i] = round_to<T>(o);          // (gd is dead from here on)
         }
     }
+    if (dxq) quantize_row_e4m3<NV>(gd, nv, lane, dxq + (int64_t)row * ldq, dxq_scale + row);
 }
 
 // dgamma[c] += sum_r dy[r,c] * xhat[r,c], dbeta[c] += sum_r dy[r,c] (the mapper's LayerNorms only: the LM is frozen).  A block owns 64
@@ -153,12 +187,14 @@ __global__ __launch_bounds__(256) void ln_dparam_kernel(int x_f32, int rows, int
 
 template <typename T>
 int ln_fwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, const float* gamma, const float* beta,
-                    float eps, void* y, int64_t ldy, float* mean, float* rstd, hipStream_t s) {
+                    float eps, void* y, int64_t ldy, float* mean, float* rstd, hipStream_t s, void* yq_ = nullptr, int64_t ldq = 0,
+                    float* yq_scale = nullptr) {
+    unsigned char* yq = reinterpret_cast<unsigned char*>(yq_);
     const int nv = (cols / 4 + 63) / 64;
     dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(256);
 #define EAVQA_LN_FWD(NV)                                                                                         \
     hipLaunchKernelGGL((ln_fwd_kernel<T, NV>), grid, block, 0, s, x_f32, rows, cols, x, ldx, gamma, beta, eps, \
-                       reinterpret_cast<T*>(y), ldy, mean, rstd)
+                       reinterpret_cast<T*>(y), ldy, mean, rstd, yq, ldq, yq_scale)
     if (nv <= 2) EAVQA_LN_FWD(2);
     else if (nv <= 4) EAVQA_LN_FWD(4);
     else if (nv <= 8) EAVQA_LN_FWD(8);
@@ -172,13 +208,15 @@ int ln_fwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, c
 template <typename T>
 int ln_bwd_dispatch(int x_f32, int rows, int cols, const void* x, int64_t ldx, const void* dy, int64_t lddy,
                     const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
-                    int64_t lddx, float* dgamma, float* dbeta, void* dx_lowp, int64_t ld_lowp, hipStream_t s) {
+                    int64_t lddx, float* dgamma, float* dbeta, void* dx_lowp, int64_t ld_lowp, hipStream_t s, void* dxq_ = nullptr,
+                    int64_t ldq = 0, float* dxq_scale = nullptr) {
+    unsigned char* dxq = reinterpret_cast<unsigned char*>(dxq_);
     const int nv = (cols / 4 + 63) / 64;
     dim3 grid((rows + LN_WAVES - 1) / LN_WAVES), block(256);
 #define EAVQA_LN_BWD(NV)                                                                                   \
     hipLaunchKernelGGL((ln_bwd_kernel<T, NV>), grid, block, 0, s, x_f32, rows, cols, x, ldx,               \
                        reinterpret_cast<const T*>(dy), lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta,  \
-                       reinterpret_cast<T*>(dx_lowp), ld_lowp)
+                       reinterpret_cast<T*>(dx_lowp), ld_lowp, dxq, ldq, dxq_scale)
     if (nv <= 2) EAVQA_LN_BWD(2);
     else if (nv <= 4) EAVQA_LN_BWD(4);
     else if (nv <= 8) EAVQA_LN_BWD(8);
@@ -321,6 +359,26 @@ extern "C" int eavqa_layernorm_bwd(int dtype, int x_f32, int rows, int cols, con
     if (dtype == EAVQA_BF16)
         return ln_bwd_dispatch<bf16_t>(x_f32, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, dgamma, dbeta, dx_lowp, ld_lowp, s);
     return EAVQA_E_DTYPE;
+}
+
+extern "C" int eavqa_layernorm_fwd_fp8(int x_kind, int rows, int cols, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                                       float eps, void* yq, int64_t ldq, float* row_scale, float* mean, float* rstd, void* stream) {
+    if (!x || !yq || !row_scale || rows <= 0 || cols <= 0) return EAVQA_E_ARG;
+    if (cols % 4 || cols > 64 * 4 * LN_MAX_V4) return EAVQA_E_SHAPE;
+    if (ldx % 4 || ldq % 4) return EAVQA_E_ALIGN;
+    if (x_kind < 1 || x_kind > 3) return EAVQA_E_DTYPE;
+    return ln_fwd_dispatch<bf16_t>(x_kind, rows, cols, x, ldx, gamma, beta, eps, nullptr, 0, mean, rstd, reinterpret_cast<hipStream_t>(stream),
+                                   yq, ldq, row_scale);
+}
+
+extern "C" int eavqa_layernorm_bwd_fp8(int x_f32, int rows, int cols, const void* x, int64_t ldx, const void* dy, int64_t lddy,
+                                       const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
+                                       void* dxq, int64_t ldq, float* row_scale, void* stream) {
+    if (!x || !dy || !dx || !mean || !rstd || !dxq || !row_scale || rows <= 0 || cols <= 0) return EAVQA_E_ARG;
+    if (cols % 4) return EAVQA_E_SHAPE;
+    if (ldx % 4 || lddy % 4 || lddx % 4 || ldq % 4) return EAVQA_E_ALIGN;
+    return ln_bwd_dispatch<bf16_t>(x_f32, rows, cols, x, ldx, dy, lddy, gamma, mean, rstd, dres, dx, lddx, nullptr, nullptr, nullptr, 0,
+                                   reinterpret_cast<hipStream_t>(stream), dxq, ldq, row_scale);
 }
 
 extern "C" int eavqa_rmsnorm_fwd(int dtype, int x_kind, int rows, int cols, const void* x, int64_t ldx, const float* gamma, float eps,

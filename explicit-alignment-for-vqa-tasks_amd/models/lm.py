@@ -179,7 +179,8 @@ def linear(a: Tensor, w, **kw) -> Tensor:
     """``epilogue(a @ w^T)``: the bf16 / fp32 MFMA GEMM, or - for an :class:`Fp8Weight` - row-wise e4m3 quantisation of ``a``
     followed by the block-scaled fp8 GEMM (eavqa_quantize_rows_fp8 + eavqa_gemm_fp8)."""
     if isinstance(w, Fp8Weight):
-        aq, a_scale = ops.quantize_rows_fp8(a)
+        # (a producer that already quantised its rows - eavqa_layernorm_fwd_fp8 / _bwd_fp8 - hands over the pair)
+        aq, a_scale = a if isinstance(a, tuple) else ops.quantize_rows_fp8(a)
         return ops.gemm_fp8(aq, a_scale, w.q, w.scale, **kw)
     return ops.gemm(a, w, **kw)
 
@@ -213,6 +214,9 @@ class FrozenCausalLM:
         # four longer GEMM epilogues per layer cost: profiles/round4_ln_fold.md), so it is an option (EAVQA_LN_FOLD=1), not the default.
         self.fold_layernorm = (dtype == torch.bfloat16 and weight_format == "native" and os.environ.get("EAVQA_LN_FOLD", "0") == "1")
         self._fold_ready = False
+        # e4m3 weights: ln_1 / ln_2 (forward) and the LayerNorm backward hand their result to the next Linear already row-quantised
+        # (EAVQA_FUSE_QUANT=0 keeps the separate eavqa_quantize_rows_fp8 launches: same bytes, the A / B switch)
+        self.fuse_quantizer = os.environ.get("EAVQA_FUSE_QUANT", "1") != "0"
 
     # ---------------------------------------------------------------- packing
     def _T(self, t: Tensor) -> Tensor:
@@ -391,6 +395,16 @@ class FrozenCausalLM:
             self._prepare_fold()
         n_slots = (E + 63) // 64
         f32 = dict(device=self.device, dtype=torch.float32)
+        fuse_q = self.weight_format == "fp8" and self.fuse_quantizer
+
+        def ln(xx, g, b, stats):
+            """ln_1 / ln_2 in front of a Linear: the bf16 operand - or, with e4m3 weights, its row-quantised form straight from the
+            LayerNorm kernel (eavqa_layernorm_fwd_fp8: the bytes eavqa_quantize_rows_fp8 would produce, one pass less)."""
+            if fuse_q:
+                r = ops.layernorm_fwd_fp8(xx, g, b, c.eps, save_stats=stats)
+                return ((r[0], r[1]), r[2], r[3]) if stats else r
+            return ops.layernorm_fwd(xx, g, b, c.eps, T, save_stats=stats)
+
         xT = st = None                                      # with `fold`: the stream in the compute dtype and its row sums (from layer 0's FFN-down on)
         for li, L in enumerate(self.layers):
             if st is not None:                              # ln_1 folded into the QKV projection
@@ -398,9 +412,9 @@ class FrozenCausalLM:
                 qkv = ops.gemm(xT, L.w_qkv_f, bias=L.d_qkv, ln_stats=st, ln_c=L.c_qkv, ln_eps=c.eps, ln_save=(mean1, rstd1) if save else None)
             else:
                 if save:
-                    a, mean1, rstd1 = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T, save_stats=True)
+                    a, mean1, rstd1 = ln(x, L.ln1_g, L.ln1_b, True)
                 else:
-                    a = ops.layernorm_fwd(x, L.ln1_g, L.ln1_b, c.eps, T)
+                    a = ln(x, L.ln1_g, L.ln1_b, False)
                 qkv = linear(a, L.w_qkv, bias=L.b_qkv)
             q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
             if save:
@@ -426,11 +440,11 @@ class FrozenCausalLM:
             else:
                 x1 = linear(ctx, L.w_o, bias=L.b_o, residual=x, out_f32=True)
                 if save:
-                    a2, mean2, rstd2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T, save_stats=True)
+                    a2, mean2, rstd2 = ln(x1, L.ln2_g, L.ln2_b, True)
                     u = torch.empty((M, c.ffn), device=self.device, dtype=T)
                     f = linear(a2, L.w_fc1, bias=L.b_fc1, act=c.act, aux_out=u)
                 else:
-                    a2 = ops.layernorm_fwd(x1, L.ln2_g, L.ln2_b, c.eps, T)
+                    a2 = ln(x1, L.ln2_g, L.ln2_b, False)
                     f = linear(a2, L.w_fc1, bias=L.b_fc1, act=c.act)
                 x2 = linear(f, L.w_fc2, bias=L.b_fc2, residual=x1, out_f32=True)
             if save:
@@ -498,19 +512,31 @@ class FrozenCausalLM:
         dhf = linear(dlog, self.head_t)                                   # [M,E] (or [n_scored,E])
         if tape.get("sel") is not None:
             dhf = ops.scatter_rows(dhf, tape["sel"], M)                      # rows without a label get no gradient here
-        dxT = torch.empty((M, E), device=self.device, dtype=T) if lowp else None
-        dx = ops.layernorm_bwd(tape["x_last"], dhf, self.lnf_g, tape["meanf"], tape["rstdf"], lowp_out=dxT)
+        fuse_q = self.weight_format == "fp8" and self.fuse_quantizer
+        if fuse_q:
+            # the copy of the stream gradient that the next dgrad GEMM multiplies leaves the LayerNorm backward already row-quantised
+            dxq = (torch.empty((M, E), device=self.device, dtype=torch.uint8), torch.empty(M, device=self.device, dtype=torch.float32))
+            dxT = dxq
+
+            def ln_bwd(xx, dy, g, mean, rstd, **kw):
+                return ops.layernorm_bwd_fp8(xx, dy, g, mean, rstd, dxq[0], dxq[1], **kw)
+        else:
+            dxT = torch.empty((M, E), device=self.device, dtype=T) if lowp else None
+
+            def ln_bwd(xx, dy, g, mean, rstd, **kw):
+                return ops.layernorm_bwd(xx, dy, g, mean, rstd, lowp_out=dxT, **kw)
+        dx = ln_bwd(tape["x_last"], dhf, self.lnf_g, tape["meanf"], tape["rstdf"])
         for L, (x, mean1, rstd1, qkv, ctx, lse, x1, mean2, rstd2, u) in zip(reversed(self.layers), reversed(tape["layers"])):
             du = linear(dxT if lowp else dx, L.w_fc2_t, act=c.act, aux_in=u)   # (dx W2) * act'(u)   [M,F]
             da2 = linear(du, L.w_fc1_t)                                    # [M,E]
-            dx1 = ops.layernorm_bwd(x1, da2, L.ln2_g, mean2, rstd2, dres=dx, out=dx, lowp_out=dxT)
+            dx1 = ln_bwd(x1, da2, L.ln2_g, mean2, rstd2, dres=dx, out=dx)
             dctx = linear(dxT if lowp else dx1, L.w_o_t)                   # [M,E]
             dqkv = torch.empty_like(qkv)
             q, k, v = qkv[:, :E], qkv[:, E:2 * E], qkv[:, 2 * E:]
             ops.attention_bwd(q, k, v, ctx, dctx, lse, B, H, S, S, hd, key_mask=mask, causal=True, scale=scale,
                               dq=dqkv[:, :E], dk=dqkv[:, E:2 * E], dv=dqkv[:, 2 * E:], cu_seqlens=cu)
             da = linear(dqkv, L.w_qkv_t)                                   # [M,E]
-            dx = ops.layernorm_bwd(x, da, L.ln1_g, mean1, rstd1, dres=dx1, out=dx1, lowp_out=dxT)
+            dx = ln_bwd(x, da, L.ln1_g, mean1, rstd1, dres=dx1, out=dx1)
         return ops.embed_assemble_bwd(tape["src"], dx, n_prefix_rows, T)
 
 

@@ -177,6 +177,40 @@ def layernorm_fwd(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ep
     return (y, mean, rstd) if save_stats else y
 
 
+def layernorm_fwd_fp8(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], eps: float, save_stats: bool = False):
+    """LayerNorm whose bf16 result leaves as e4m3 rows + row scales (``layernorm_fwd`` followed by ``quantize_rows_fp8``, one kernel):
+    ``(q uint8 [rows, cols], scale float32 [rows])`` (+ mean, rstd)."""
+    _dev(x)
+    rows, cols = x.shape
+    q = torch.empty((rows, cols), device=x.device, dtype=torch.uint8)
+    sc = torch.empty(rows, device=x.device, dtype=torch.float32)
+    mean = rstd = None
+    if save_stats:
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    x_kind = {torch.float32: 1, torch.bfloat16: 2, torch.float16: 3}.get(x.dtype)
+    if x_kind is None:
+        raise _lib.EavqaError(f"unsupported layernorm input dtype {x.dtype}")
+    call("eavqa_layernorm_fwd_fp8", x_kind, rows, cols, _p(x), _ld(x), _p(gamma), _p(beta), float(eps), _p(q), _ld(q), _p(sc), _p(mean), _p(rstd),
+         _stream())
+    return (q, sc, mean, rstd) if save_stats else (q, sc)
+
+
+def layernorm_bwd_fp8(x: Tensor, dy: Tensor, gamma: Optional[Tensor], mean: Tensor, rstd: Tensor, q_out: Tensor, scale_out: Tensor,
+                      dres: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """``layernorm_bwd`` whose bf16 copy of dx leaves as e4m3 rows + row scales into ``q_out`` (uint8 [rows, cols]) / ``scale_out``."""
+    _dev(x)
+    rows, cols = x.shape
+    if dy.dtype != torch.bfloat16:
+        raise _lib.EavqaError("layernorm_bwd_fp8: dy must be bfloat16")
+    dx = out if out is not None else torch.empty((rows, cols), device=x.device, dtype=torch.float32)
+    if dres is not None and _ld(dres) != _ld(dx):
+        raise _lib.EavqaError("dres must share dx's leading dimension")
+    call("eavqa_layernorm_bwd_fp8", int(x.dtype == torch.float32), rows, cols, _p(x), _ld(x), _p(dy), _ld(dy), _p(gamma), _p(mean), _p(rstd),
+         _p(dres), _p(dx), _ld(dx), _p(q_out), _ld(q_out), _p(scale_out), _stream())
+    return dx
+
+
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], mean: Tensor, rstd: Tensor,
                   dres: Optional[Tensor] = None, dgamma: Optional[Tensor] = None, dbeta: Optional[Tensor] = None,
                   out: Optional[Tensor] = None, lowp_out: Optional[Tensor] = None) -> Tensor:

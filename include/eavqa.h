@@ -140,6 +140,16 @@ int eavqa_layernorm_bwd(int dtype, int x_f32, int rows, int cols, const void* x,
                         const float* mean, const float* rstd,
                         const float* dres, float* dx, int64_t lddx,
                         float* dgamma, float* dbeta, void* dx_lowp, int64_t ld_lowp, void* stream);
+/* eavqa_layernorm_fwd / _bwd with the row quantiser of the fp8 path fused in (round 4; BASELINE configs[4]): the result that would have been
+ * written in bfloat16 and read back by eavqa_quantize_rows_fp8 leaves as e4m3 bytes + one float32 scale per row (scale = amax / 448 of the
+ * bf16-rounded row, 1 for an all-zero row) - the same bytes and scales as the two-kernel sequence, one pass over the row less.
+ * x_kind as in eavqa_layernorm_fwd (1 float32, 2 bfloat16, 3 half); the backward's dy is bfloat16, dx stays float32. */
+int eavqa_layernorm_fwd_fp8(int x_kind, int rows, int cols, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                            float eps, void* yq, int64_t ldq, float* row_scale, float* mean, float* rstd, void* stream);
+int eavqa_layernorm_bwd_fp8(int x_f32, int rows, int cols, const void* x, int64_t ldx, const void* dy, int64_t lddy,
+                            const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx, int64_t lddx,
+                            void* dxq, int64_t ldq, float* row_scale, void* stream);
+
 
 /* ----------------------------------------------------------- attention ---
  * softmax(scale * q k^T + mask) v per (batch, head); eager formula

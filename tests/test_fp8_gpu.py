@@ -316,6 +316,71 @@ def test_layernorm_splitk_fp8_is_layernorm_then_row_quantiser(rows, cols, ks):
     assert torch.equal(x1, x2) and torch.equal(sc, s_ref) and torch.equal(q, q_ref)
 
 
+@pytest.mark.parametrize("rows,cols", [(1943, 1280), (2048, 4096), (7, 128), (130, 2048), (33, 520)])
+@pytest.mark.parametrize("x_dtype", [torch.float32, torch.bfloat16])
+def test_layernorm_fwd_bwd_fp8_are_the_kernel_pairs_they_replace(rows, cols, x_dtype):
+    """eavqa_layernorm_fwd_fp8 == eavqa_layernorm_fwd (bf16 out) + eavqa_quantize_rows_fp8 and eavqa_layernorm_bwd_fp8 ==
+    eavqa_layernorm_bwd (bf16 copy of dx) + eavqa_quantize_rows_fp8: bytes, row scales, statistics and the fp32 dx, bit for bit."""
+    from eavqa_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 1.5 + 0.3).to(x_dtype).to(DEV)
+    x[rows // 2] = 0                                                       # a constant row: xhat = 0, the output is beta
+    gamma, beta = (1 + 0.2 * torch.randn(cols, generator=g)).to(DEV), (0.1 * torch.randn(cols, generator=g)).to(DEV)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-5, torch.bfloat16, save_stats=True)
+    q_ref, s_ref = ops.quantize_rows_fp8(y)
+    q, sc, mean2, rstd2 = ops.layernorm_fwd_fp8(x, gamma, beta, 1e-5, save_stats=True)
+    q3, sc3 = ops.layernorm_fwd_fp8(x, gamma, beta, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.equal(q, q_ref) and torch.equal(sc, s_ref) and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    assert torch.equal(q3, q_ref) and torch.equal(sc3, s_ref)
+    if cols > 4096:
+        return
+    dy = (torch.randn(rows, cols, generator=g) * 0.01).to(torch.bfloat16).to(DEV)
+    dy[0] = 0                                                              # an all-zero gradient row: scale 1, zero bytes
+    dres = torch.randn(rows, cols, generator=g).to(DEV) * 0.01
+    dres[0] = 0
+    lowp = torch.empty((rows, cols), device=DEV, dtype=torch.bfloat16)
+    dx_ref = ops.layernorm_bwd(x, dy, gamma, mean, rstd, dres=dres, lowp_out=lowp)
+    dq_ref, ds_ref = ops.quantize_rows_fp8(lowp)
+    dq, ds = torch.empty((rows, cols), device=DEV, dtype=torch.uint8), torch.empty(rows, device=DEV)
+    dx = ops.layernorm_bwd_fp8(x, dy, gamma, mean, rstd, dq, ds, dres=dres)
+    torch.cuda.synchronize()
+    assert torch.equal(dx, dx_ref) and torch.equal(dq, dq_ref) and torch.equal(ds, ds_ref)
+    assert ds[0].item() == 1.0 and int(dq[0].max().item()) == 0
+
+
+@pytest.mark.parametrize("arch", ["opt", "gpt2"])
+def test_fp8_training_step_is_bit_equal_with_and_without_the_fused_quantiser(arch):
+    """``FrozenCausalLM.fuse_quantizer``: the fp8 training step with LayerNorm (forward and backward) handing over quantised rows against the
+    same step with the separate eavqa_quantize_rows_fp8 launches - same bytes into every GEMM, so loss, logits and gradients are identical."""
+    from eavqa_amd.models.clipcap import ClipCaptionPrefix
+    from eavqa_amd.models.lm import FrozenCausalLM, LMConfig, random_init_state_dict
+    E, H, F, NL, V, L, D, B, T = 256, 4, 512, 3, 640, 4, 32, 6, 24
+    cfg = (LMConfig("opt", NL, H, E, F, V, 64, 1e-5, "relu", 2, 1) if arch == "opt" else LMConfig("gpt2", NL, H, E, F, V, 64, 1e-5, "gelu_new", V - 1, None))
+    sd = random_init_state_dict(cfg, 7, "cpu")
+    g = torch.Generator().manual_seed(2)
+    lens = torch.randint(6, T + 1, (B,), generator=g); lens[0] = T
+    pad = V - 1
+    ids = torch.randint(3, V - 2, (B, T), generator=g)
+    mask = (torch.arange(T)[None] < lens[:, None]).long()
+    ids = ids * mask + pad * (1 - mask)
+    labels = oracle.label_mask_cc(ids, pad)
+    prefix = torch.randn(B, D, generator=g)
+    res = []
+    for fuse in (True, False):
+        lm = FrozenCausalLM(cfg, sd, torch.bfloat16, DEV, weight_format="fp8")
+        assert lm.fuse_quantizer                                           # the default
+        lm.fuse_quantizer = fuse
+        torch.manual_seed(1)
+        model = ClipCaptionPrefix(prefix_length=L, prefix_size=D, mapping_type="mlp", lm=lm, dtype=torch.bfloat16, device=DEV).train()
+        out = model(question_tokens=ids, prefix=prefix, question_mask=mask, labels=labels)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res.append((out.loss.item(), out.logits.float().cpu(), [p.grad.float().cpu().clone() for p in model.clip_project.parameters()]))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+
+
 @pytest.mark.parametrize("arch", ["opt", "gpt2"])
 def test_fp8_lm_cached_generation_returns_the_ids_of_the_reforward_loop(arch):
     """``generate()`` (use_cache=True by default) on an LM held in e4m3: prefill + cached decode steps through ``eavqa_lm_block_forward_fp8``
