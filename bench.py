@@ -175,7 +175,7 @@ FEWSHOT = dict(vit="ViT-L/14", lm="facebook/opt-2.7b", prefix_length=10, batch=3
                     "(5 images/question), 20 text tokens per segment, prompt 150 positions after prefix insertion, 10 new tokens")
 
 
-def fewshot_qps(dtype, device, reps=3):
+def fewshot_qps(dtype, device, reps=6, encode_ahead=True):
     """Questions/s of the few-shot generate path (metric M2): ViT encode of 5 images per question, MLP mapper,
     sentinel expansion (insert_prefix_into_input), prefill, 10 greedy steps with a KV cache."""
     from eavqa_amd.data.synthetic import fewshot_batch
@@ -204,13 +204,13 @@ def fewshot_qps(dtype, device, reps=3):
         return model.generate_fewshot(b["input_ids"], emb, b["attention_mask"], num_shots=f["shots"], special_token_id=sentinel,
                                       max_length=f["new_tokens"], pad_token_id=lcfg.pad_token_id, eos_token_id=None, marks=marks)
 
+    def generate(emb):
+        return model.generate_fewshot(b["input_ids"], emb.view(B, n_img, -1), b["attention_mask"], num_shots=f["shots"], special_token_id=sentinel,
+                                      max_length=f["new_tokens"], pad_token_id=lcfg.pad_token_id, eos_token_id=None)
+
     run()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        out = run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    out, dt = _timed_batches(vit, b["pixel_values"].reshape(B * n_img, *b["pixel_values"].shape[2:]), generate, reps, encode_ahead)
     assert len(out) == B and len(out[0]) == f["new_tokens"]
     # per-phase roofline of one more, instrumented batch (HIP events on the launch stream; a ~40 ms head start of queued work
     # keeps host latency out of the brackets, as in gemm_roofline)
@@ -248,12 +248,35 @@ def fewshot_qps(dtype, device, reps=3):
     del model, lm, vit
     torch.cuda.empty_cache()
     return {"metric": "fewshot_vqa_questions_per_sec", "value": round(B / dt, 2), "unit": "questions/s", "ms_per_batch": round(dt * 1e3, 2),
-            "config": {"workload": "few-shot cfg4: " + f["desc"], "batch": B, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "kv_cache": True},
+            "config": {"workload": "few-shot cfg4: " + f["desc"], "batch": B, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "kv_cache": True,
+                       "batches_timed": reps, "encode_ahead": bool(encode_ahead)},
             "roofline": roof}
 
 
 T0 = dict(vit="ViT-L/14", lm="bigscience/T0_3B", prefix_length=10, fewshot_batch=32, shots=4, seg_len=20, new_tokens=10, train_batch=64, text_len=32,
           desc="the reference's headline model (SURVEY F2): CLIP ViT-L/14 -> MLP mapper -> T0_3B (T5 v1.1 XL encoder-decoder), VCT0Prefix, prefix 10")
+
+
+def _timed_batches(vit, px, generate, reps, encode_ahead):
+    """``reps`` batches of (image tower -> generate) back to back, wall clock per batch.  With ``encode_ahead`` the tower of batch i + 1 is
+    issued on a second stream before batch i is generated (models/clip_vit.py::EncodeAhead; the first batch's tower is inside the timed
+    region and overlaps nothing), otherwise the plain sequential loop."""
+    from eavqa_amd.models.clip_vit import EncodeAhead
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if encode_ahead:
+        ahead = EncodeAhead(vit)
+        ticket = ahead.submit(px)
+        for i in range(reps):
+            emb = ahead.result(ticket)
+            if i + 1 < reps:
+                ticket = ahead.submit(px)
+            out = generate(emb)
+    else:
+        for _ in range(reps):
+            out = generate(vit.encode_image(px))
+    torch.cuda.synchronize()
+    return out, (time.perf_counter() - t0) / reps
 
 
 def _t0_models(dtype, device, train):
@@ -278,7 +301,7 @@ def _t5_stack_flops(c, enc_pos, dec_pos):
     return enc, dec
 
 
-def t0_fewshot_qps(dtype, device, reps=3):
+def t0_fewshot_qps(dtype, device, reps=6, encode_ahead=True):
     """Few-shot VQA2 generate with the reference's own model (few_shot_vqa_executor.py:195-205 -> VCT0Model.generate, vct0.py:396-491):
     32 questions x (4 shots + query), ViT-L/14 encode of 5 images per question, MLP mapper, sentinel expansion, T5 encoder over the 150
     interleaved positions, cross K / V of 24 decoder layers once, 9 cached greedy decoder steps (max_length 10)."""
@@ -297,11 +320,9 @@ def t0_fewshot_qps(dtype, device, reps=3):
 
     out = run()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        out = run()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    out, dt = _timed_batches(vit, px, lambda emb: model.generate(prefix=emb.view(B, n_img, -1), question_tokens=b["input_ids"],
+                                                                  question_mask=b["attention_mask"], num_shots=shots, max_length=new),
+                             reps, encode_ahead)
     assert tuple(out.shape) == (B, new)
     # phases of one more batch, each bracketed by HIP events on the launch stream behind a head start of queued work
     blk = torch.randn(8192, 8192, device=device).to(torch.bfloat16)
@@ -352,7 +373,8 @@ def t0_fewshot_qps(dtype, device, reps=3):
     torch.cuda.empty_cache()
     return {"metric": "fewshot_vqa_questions_per_sec", "value": round(B / dt, 2), "unit": "questions/s", "ms_per_batch": round(dt * 1e3, 2),
             "config": {"workload": "t0_3b_fewshot: " + T0["desc"] + "; 4 in-context shots + query (5 images / question), 20 text tokens per segment, "
-                                   "150 encoder positions, max_length 10", "batch": B, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "kv_cache": True},
+                                   "150 encoder positions, max_length 10", "batch": B, "dtype": "bf16" if dtype == torch.bfloat16 else "f32", "kv_cache": True,
+                       "batches_timed": reps, "encode_ahead": bool(encode_ahead)},
             "roofline": roof}
 
 
@@ -599,7 +621,7 @@ def main():
                          "all-gather, 'allreduce' = flat gradient all-reduce; 'auto' takes the cheapest under the cost model of "
                          "eavqa_amd.trainers.optim.choose_dp_exchange (DESIGN.md section 7)")
     ap.add_argument("--mapping-type", choices=["mlp", "transformer"], default=None, help="override the workload's mapper")
-    ap.add_argument("--no-overlap", action="store_true", help="run the CLIP encode on the main stream (no cross-step pipelining)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the CLIP encode on the main stream (no cross-step pipelining in the training legs, no look-ahead encode in the few-shot legs)")
     ap.add_argument("--no-fewshot", action="store_true", help="skip the few-shot generate leg (metric M2, reported under 'extra')")
     ap.add_argument("--no-extra-train", action="store_true",
                     help="skip the short cfg3 (bf16) and cfg5 (fp8) training legs that the default cfg2 run reports under 'extra'")
@@ -644,7 +666,7 @@ def main():
     if solo and not args.no_fewshot:
         try:
             log("few-shot generate leg ...")
-            extra.append(fewshot_qps(dtype, device))
+            extra.append(fewshot_qps(dtype, device, encode_ahead=not args.no_overlap))
             log(f"few-shot leg done: {extra[-1]}")
         except Exception as e:                # never lose the headline line to a secondary metric
             extra.append({"metric": "fewshot_vqa_questions_per_sec", "error": repr(e)[:300]})
@@ -657,7 +679,7 @@ def main():
                 extra.append({"metric": "mapper_train_samples_per_sec", "config": {"workload": name}, "dtype": dt_name, "error": repr(e)[:300]})
                 torch.cuda.empty_cache()
     if solo and not args.no_t0 and args.workload == "cfg2" and args.dtype == "bf16" and not args.mapping_type:
-        for name, fn in (("t0_3b_fewshot", lambda: t0_fewshot_qps(dtype, device)), ("t0_3b_cc_train", lambda: t0_cc_train_leg("bf16", 10, 5, device, args))):
+        for name, fn in (("t0_3b_fewshot", lambda: t0_fewshot_qps(dtype, device, encode_ahead=not args.no_overlap)), ("t0_3b_cc_train", lambda: t0_cc_train_leg("bf16", 10, 5, device, args))):
             try:
                 log(f"{name} leg ...")
                 extra.append(fn())

@@ -510,3 +510,34 @@ def test_folded_layernorm_training_step_matches_the_layernorm_kernels_bf16(arch,
         want = mapper[k].grad
         e = {f: (res[f][2][k] - want).abs().max().item() for f in res}
         assert e[True] <= max(1.5 * e[False], 2e-2 * want.abs().max().item()), (k, e)
+
+
+def test_encode_ahead_returns_the_embeddings_and_ids_of_the_sequential_loop():
+    """``EncodeAhead`` (the image tower of batch i + 1 on a second stream while batch i is generated): embeddings bit-equal with
+    ``encode_image`` on the calling stream, generated ids equal over three pipelined batches with different images."""
+    from eavqa_amd.models.clip_vit import ClipVisionEncoder, EncodeAhead, ViTConfig, random_init_vit_state_dict
+    from eavqa_amd.models.clipcap import ClipCaptionPrefix
+    from eavqa_amd.models.lm import FrozenCausalLM
+    vcfg = ViTConfig(64, 2, 2, 128, 8, 32, 24)                     # width, layers, heads, mlp, patch, image, projection
+    vit = ClipVisionEncoder(vcfg, random_init_vit_state_dict(vcfg, 5, DEV), torch.bfloat16, DEV)
+    cfg, sd = _tiny_lm(V=160, E=64, n_layer=2, n_head=4)
+    lm = FrozenCausalLM(cfg, sd, torch.bfloat16, DEV)
+    torch.manual_seed(1)
+    model = ClipCaptionPrefix(prefix_length=3, prefix_size=24, mapping_type="mlp", lm=lm, dtype=torch.bfloat16, device=DEV).eval()
+    g = torch.Generator().manual_seed(4)
+    B, T, n = 5, 7, 3
+    px = [torch.randn(B, 3, 32, 32, generator=g).to(DEV) for _ in range(n)]
+    ids = torch.randint(3, 150, (B, T), generator=g).to(DEV)
+    mask = torch.ones(B, T, dtype=torch.long, device=DEV)
+    gen = lambda emb: model.generate(question_tokens=ids, prefix=emb, question_mask=mask, max_length=6, pad_token_id=0)
+    want_emb = [vit.encode_image(p) for p in px]
+    want = [gen(e) for e in want_emb]
+    ahead = EncodeAhead(vit)
+    ticket = ahead.submit(px[0])
+    for i in range(n):
+        emb = ahead.result(ticket)
+        if i + 1 < n:
+            ticket = ahead.submit(px[i + 1])
+        got = gen(emb)
+        torch.cuda.synchronize()
+        assert torch.equal(emb, want_emb[i]) and got == want[i], i
