@@ -36,6 +36,10 @@ SHAPES = [  # (M, N, K, what)
     (32, 6144, 2048, "t5dec qkv"), (32, 2048, 2048, "t5dec o"), (32, 10240, 2048, "t5dec wi"), (32, 2048, 5120, "t5dec wo"),
     (160, 6144, 2048, "t5dec5 qkv"), (160, 2048, 2048, "t5dec5 o"), (160, 10240, 2048, "t5dec5 wi"), (160, 2048, 5120, "t5dec5 wo"),
     (288, 2048, 2048, "t5dec9 o"), (288, 2048, 5120, "t5dec9 wo"),
+    (640, 6144, 2048, "t0enc qkv"), (640, 2048, 2048, "t0enc o"), (640, 10240, 2048, "t0enc wi"), (640, 2048, 5120, "t0enc wo"),
+    (640, 2048, 6144, "t0enc dqkv"), (640, 2048, 10240, "t0enc dwi"), (640, 5120, 2048, "t0enc dwo"), (640, 4096, 2048, "t0enc crosskv"),
+    (2048, 2048, 2048, "t0dec o"), (2048, 2048, 5120, "t0dec wo"), (2048, 6144, 2048, "t0dec qkv"), (2048, 10240, 2048, "t0dec wi"),
+    (2048, 2048, 10240, "t0dec dwi"), (168, 768, 768, "cfg1B4 proj"), (168, 3072, 768, "cfg1B4 fc1"), (168, 768, 3072, "cfg1B4 fc2"),
     (3200, 3072, 768, "vit fc1"), (3200, 768, 3072, "vit fc2"), (4096, 4096, 4096, "square 4k"), (8192, 8192, 8192, "square 8k"),
 ]
 
