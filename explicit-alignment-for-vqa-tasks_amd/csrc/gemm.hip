@@ -463,7 +463,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     float2* rowstat = reinterpret_cast<float2*>(smem + CS_BYTES);          // present when launched with ln_lds(p) extra bytes
     ln_rowstat_fill(p, rowstat, m0, n0, BM, tid, 256);
     __syncthreads();
-    epilogue_any<bf16_t>(p, Cs, m0, n0, LnArgs{rowstat, 0});
+    if constexpr (A_KC && B_KC) epilogue_any<bf16_t>(p, Cs, m0, n0, LnArgs{rowstat, 0});       // (the other layouts do without the eavqa_gemm_ln form: compile time)
+    else epilogue<bf16_t, EpiGeo128, false>(p, Cs, m0, n0);
 }
 
 
@@ -649,7 +650,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_fast_kernel(GemmParams p, in
                 Cs[row * CS_PITCH + col] = acc[i][j][r];
             }
     __syncthreads();
-    epilogue_any<bf16_t>(p, Cs, m0, n0);
+    epilogue<bf16_t, EpiGeo128, false>(p, Cs, m0, n0);
 }
 #undef EAVQA_FAST_STEP
 
@@ -877,7 +878,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN <= 4) ? 2 : 1) void gemm_bf1
                     }
         }
         __syncthreads();
-        epilogue_any<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>>(p, Cs, m0 + pass * G::PROWS, n0);
+        epilogue<bf16_t, EpiGeo<G::TPR, G::RPP, G::NPASS, G::PITCH, G::PROWS>, false>(p, Cs, m0 + pass * G::PROWS, n0);
         if (pass + 1 < WM / G::SP) __syncthreads();
     }
 }
@@ -1334,7 +1335,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     float2* rowstat = reinterpret_cast<float2*>(smem + CS_BYTES);          // present when launched with ln_lds(p) extra bytes
     ln_rowstat_fill(p, rowstat, m0, n0, BM, tid, 256);
     __syncthreads();
-    epilogue_any<float>(p, Cs, m0, n0, LnArgs{rowstat, 0});
+    if constexpr (A_KC && B_KC) epilogue_any<float>(p, Cs, m0, n0, LnArgs{rowstat, 0});
+    else epilogue<float, EpiGeo128, false>(p, Cs, m0, n0);
 }
 
 typedef void (*gemm_kernel_t)(GemmParams);
@@ -1388,7 +1390,7 @@ int gemm_impl(int dtype, int a_kc, int b_kc, int M, int N, int K,
         if (ln->stats_out && ln->stats_ld < (N + 63) / 64) return EAVQA_E_ARG;
         if (ln_consumer && (!ln->ln_c || ln->ln_parts <= 0 || ln->ln_ld < ln->ln_parts || ln->ln_cols <= 0 || !(ln->ln_eps >= 0.f))) return EAVQA_E_ARG;
         if ((ln->mean_out != nullptr) != (ln->rstd_out != nullptr) || (ln->mean_out && !ln_consumer)) return EAVQA_E_ARG;
-        if (ln_consumer && !(a_kc && b_kc)) return EAVQA_E_SHAPE;
+        if (!(a_kc && b_kc)) return EAVQA_E_SHAPE;          // the eavqa_gemm_ln form exists for k-contiguous operands (the frozen LM's Linear layers)
     }
     if (out_flags & ~(EAVQA_GEMM_OUT_F32 | EAVQA_GEMM_RESIDUAL_LOWP | EAVQA_GEMM_STREAM_F16)) return EAVQA_E_ARG;
     if ((out_flags & (EAVQA_GEMM_RESIDUAL_LOWP | EAVQA_GEMM_STREAM_F16)) && dtype != EAVQA_BF16) return EAVQA_E_DTYPE;   // 16-bit streams: bf16 operands only
@@ -1493,7 +1495,7 @@ int gemm_impl(int dtype, int a_kc, int b_kc, int M, int N, int K,
             if (M > 64 && big_cost < best) return run_big(p);
             return K64_SHAPES[pick].launch(p, s);
         }
-        if (a_kc && b_kc && !kn.disable_fast && (K % FBK) == 0 && !ln_consumer) {      // (those kernels carry no row statistics: the general kernel below does)
+        if (a_kc && b_kc && !kn.disable_fast && (K % FBK) == 0 && !ln) {      // (the round-1 BK = 32 kernels have no eavqa_gemm_ln form: the general kernel below does)
             if (kn.shape_mode >= 2 && kn.shape_mode < 7) return SHAPES[kn.shape_mode - 2].launch(p, s);
             const bool big_ok = (K % GBK) == 0 && kn.big_mode != 1;
             if (big_ok && kn.big_mode == 2) return run_big(p);

@@ -217,27 +217,38 @@ __global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(Gem
     k64s_store_tile<G, WM, WN, MF, NF, LNX>(p, acc, smem, wave, lane, m0, n0, rowstat);
 }
 
-template <int WM, int WN, int MF, int NF, int NST, int LW>
+// WITH_LN: also instantiate the eavqa_gemm_ln form of this tile (the tiles the dispatcher picks from; the knob-only experiments do without -
+// every instantiation costs half a minute of compile time - and answer EAVQA_E_SHAPE to an eavqa_gemm_ln_ex call that forces them)
+template <int WM, int WN, int MF, int NF, int NST, int LW, bool WITH_LN = false>
 int launch_k64s(const GemmParams& p, hipStream_t stream) {
     using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
+    const bool ln = p.ln_stats || p.stats_out || p.copy_out;
+    if (ln && !WITH_LN) return EAVQA_E_SHAPE;
     static std::atomic<bool> configured{false};        // atomic: concurrent first calls only repeat an idempotent call
     if (!configured.load(std::memory_order_acquire)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, G::RING + LN_ROWSTAT_BYTES) != hipSuccess)
+                                hipFuncAttributeMaxDynamicSharedMemorySize, G::RING) != hipSuccess)
             return EAVQA_E_LAUNCH;
+        if constexpr (WITH_LN) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, G::RING + LN_ROWSTAT_BYTES) != hipSuccess)
+                return EAVQA_E_LAUNCH;
+        }
         configured.store(true, std::memory_order_release);
     }
-    static_assert(G::RING + LN_ROWSTAT_BYTES <= 160 * 1024, "ring + row statistics of eavqa_gemm_ln");
+    static_assert(!WITH_LN || G::RING + LN_ROWSTAT_BYTES <= 160 * 1024, "ring + row statistics of eavqa_gemm_ln");
     const int tiles_m = (p.M + G::TBM - 1) / G::TBM, tiles_n = (p.N + G::TBN - 1) / G::TBN;
     const GridPlan g = plan_grid(tiles_m, tiles_n, G::TBM, G::TBN);
-    if (p.ln_stats || p.stats_out || p.copy_out)
-        hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, true>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING + ln_lds(p), stream, p,
-                           g.gx, g.gy, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, false>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
-                           tiles_m, tiles_n);
+    if constexpr (WITH_LN) {
+        if (ln) {
+            hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, true>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING + ln_lds(p), stream, p,
+                               g.gx, g.gy, tiles_m, tiles_n);
+            EAVQA_LAUNCH_CHECK();
+            return EAVQA_OK;
+        }
+    }
+    hipLaunchKernelGGL((gemm_bf16_k64s_kernel<WM, WN, MF, NF, NST, LW, false>), dim3(g.per_xcd * 8), dim3(G::NT), G::RING, stream, p, g.gx, g.gy,
+                       tiles_m, tiles_n);
     EAVQA_LAUNCH_CHECK();
     return EAVQA_OK;
 }
@@ -249,14 +260,14 @@ const K64Choice K64_SHAPES[] = {
     {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 2>},          //  2
     {128, 80, 2, 1.1f, launch_k64s<4, 1, 2, 5, 3, 4>},          //  3
     {128, 128, 2, 1.1f, launch_k64s<2, 2, 4, 4, 2, 4>},         //  4
-    {256, 128, 1, 1.97f, launch_k64s<4, 2, 4, 4, 3, 4>},        //  5
-    {256, 160, 1, 1.93f, launch_k64s<4, 2, 4, 5, 3, 4>},        //  6
-    {128, 80, 1, 1.56f, launch_k64s<4, 1, 2, 5, 4, 2>},         //  7: four stages (one workgroup per CU)
+    {256, 128, 1, 1.97f, launch_k64s<4, 2, 4, 4, 3, 4, true>},  //  5
+    {256, 160, 1, 1.93f, launch_k64s<4, 2, 4, 5, 3, 4, true>},  //  6
+    {128, 80, 1, 1.56f, launch_k64s<4, 1, 2, 5, 4, 2, true>},   //  7: four stages (one workgroup per CU)
     {128, 96, 1, 1.1f, launch_k64s<4, 1, 2, 6, 3, 2>},          //  8
     {256, 192, 1, 1.1f, launch_k64s<4, 2, 4, 6, 2, 4>},         //  9
     {256, 256, 1, 1.1f, launch_k64s<2, 4, 8, 4, 2, 4>},         // 10
-    {128, 128, 1, 1.73f, launch_k64s<2, 2, 4, 4, 3, 2>},        // 11: three stages
-    {128, 256, 1, 1.97f, launch_k64s<2, 4, 4, 4, 3, 4>},        // 12
+    {128, 128, 1, 1.73f, launch_k64s<2, 2, 4, 4, 3, 2, true>},  // 11: three stages
+    {128, 256, 1, 1.97f, launch_k64s<2, 4, 4, 4, 3, 4, true>},  // 12
 };
 constexpr int N_K64 = sizeof(K64_SHAPES) / sizeof(K64_SHAPES[0]);
 // the tiles the dispatcher chooses among (indices into K64_SHAPES): s128x80 (4 stages), s256x128, s256x160, s128x128 (3 stages), s128x256

@@ -99,14 +99,14 @@ int eavqa_gemm(int dtype, int a_kc, int b_kc, int M, int N, int K,
  *     stats_out != NULL: float32 [M, stats_ld, 2], stats_ld >= ceil(N / 64): (sum, sum of squares) of every result row (of the values as
  *                        stored in C before any rounding) spread over 64-column slots - a tile writes its whole sum into its first slot and
  *                        zeros into the others, so the consumer adds all stats_ld slots whatever tile width produced them;
- *   consumer (QKV projection, FFN-up), a_kc and b_kc forms only:
+ *   consumer (QKV projection, FFN-up):
  *     ln_stats != NULL: the producer's stats (leading dimension ln_ld slots, ln_parts of them summed), ln_cols = the length of a stream
  *                       row; A = the UN-normalised rows in `dtype`, B = W', bias = d, ln_c = c (float32 [N]):
  *                       v = rstd[m] (alpha acc - mean[m] c[n]) + bias[n], then the rest of eavqa_gemm's epilogue;
  *                       mean = sum / ln_cols, rstd = 1 / sqrt(sumsq / ln_cols - mean^2 + ln_eps);
  *     mean_out / rstd_out (both or neither): float32 [M], what eavqa_layernorm_fwd would have saved for eavqa_layernorm_bwd.
- * Either side may be used alone; every pointer of `ln` may be NULL.  Not available with the M <= 64 weight-streaming kernel (the call
- * takes a tiled kernel instead). */
+ * Either side may be used alone; every pointer of `ln` may be NULL.  k-contiguous operands only (a_kc and b_kc non-zero: the Linear layers of
+ * a frozen LM); not available with the M <= 64 weight-streaming kernel (the call takes a tiled kernel instead). */
 typedef struct {
     void* copy_out; int64_t ld_copy;
     float* stats_out; int32_t stats_ld;

@@ -18,9 +18,9 @@ DEV = "cuda"
 ACTS = {"none": lambda x: x, "relu": torch.relu, "gelu_new": oracle.gelu_new}
 
 # kernel selectors of include/eavqa_test.h: [13:8] forces a full-line (BK = 64) tile, [15:14] = 2 the 256 x 256 kernel, bit 7 the general
-# kernel, [20:18] a round-1 shaped tile (producer side only)
-K64 = {f"k64_{i}": i << 8 for i in (2, 4, 5, 6, 7, 8, 11, 12)}        # knob ids of K64_SHAPES (gemm_k64.hip)
-PRODUCER_KNOBS = {"auto": 0, "big": 2 << 14, "general": 1 << 7, "shaped128x80": 2 << 18, "shaped256x160": 5 << 18, **K64}
+# kernel
+K64 = {f"k64_{i}": i << 8 for i in (5, 6, 7, 11, 12)}        # knob ids of K64_SHAPES (gemm_k64.hip): the tiles the dispatcher picks from carry the LN form
+PRODUCER_KNOBS = {"auto": 0, "big": 2 << 14, "general": 1 << 7, **K64}
 CONSUMER_KNOBS = {"auto": 0, "big": 2 << 14, "general": 1 << 7, **K64}
 
 
@@ -163,9 +163,13 @@ def test_fp32_operands(ops):
     assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * math.sqrt(K)
 
 
-def test_rejects_bad_arguments(ops):
+def test_rejects_bad_arguments(ops, knob):
     from eavqa_amd import _lib
     a, b = torch.zeros((128, 64), device=DEV, dtype=torch.bfloat16), torch.zeros((256, 64), device=DEV, dtype=torch.bfloat16)
+    knob(2 << 8)                                                                            # a knob-only tile has no LN form
+    with pytest.raises(_lib.EavqaError, match="shape"):
+        ops.gemm(a, b, stats_out=torch.zeros((128, 4, 2), device=DEV))
+    knob(0)
     with pytest.raises(_lib.EavqaError):
         ops.gemm(a, b, stats_out=torch.zeros((128, 3, 2), device=DEV))                     # fewer than ceil(N / 64) slots
     with pytest.raises(_lib.EavqaError):
