@@ -9,11 +9,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(int64_t n4, int64_t n, float
                                                     float lr, float beta1, float beta2, float eps, float decay_mul,
                                                     float inv_bc1, float inv_sqrt_bc2, float grad_scale, S* shadow) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-        float4 p = reinterpret_cast<float4*>(param)[i];
-        const float4 g = reinterpret_cast<const float4*>(grad)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i];
-        float4 vv = reinterpret_cast<float4*>(v)[i];
+    auto update = [&](float4& p, const float4 g, float4& mm, float4& vv) {
         float pa[4] = {p.x, p.y, p.z, p.w}, ga[4] = {g.x, g.y, g.z, g.w};
         float ma[4] = {mm.x, mm.y, mm.z, mm.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
@@ -25,10 +21,32 @@ __global__ __launch_bounds__(256) void adamw_kernel(int64_t n4, int64_t n, float
             const float denom = sqrtf(va[j]) * inv_sqrt_bc2 + eps;
             pa[j] -= (lr * inv_bc1) * (ma[j] / denom);
         }
-        reinterpret_cast<float4*>(param)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
-        reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
-        reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
-        if (HAS_SHADOW) elem<S>::st4(shadow + 4 * i, make_float4(pa[0], pa[1], pa[2], pa[3]));
+        p = make_float4(pa[0], pa[1], pa[2], pa[3]);
+        mm = make_float4(ma[0], ma[1], ma[2], ma[3]);
+        vv = make_float4(va[0], va[1], va[2], va[3]);
+    };
+    // two grid strides per iteration: eight 16-byte loads in flight per thread before the first use (the update is element-wise, so
+    // the order in which elements are visited does not change any result)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+        const int64_t i2 = i + stride;
+        const bool two = i2 < n4;
+        const int64_t j2 = two ? i2 : i;
+        float4 p0 = reinterpret_cast<float4*>(param)[i], p1 = reinterpret_cast<float4*>(param)[j2];
+        const float4 g0 = reinterpret_cast<const float4*>(grad)[i], g1 = reinterpret_cast<const float4*>(grad)[j2];
+        float4 m0 = reinterpret_cast<float4*>(m)[i], m1 = reinterpret_cast<float4*>(m)[j2];
+        float4 v0 = reinterpret_cast<float4*>(v)[i], v1 = reinterpret_cast<float4*>(v)[j2];
+        update(p0, g0, m0, v0);
+        reinterpret_cast<float4*>(param)[i] = p0;
+        reinterpret_cast<float4*>(m)[i] = m0;
+        reinterpret_cast<float4*>(v)[i] = v0;
+        if (HAS_SHADOW) elem<S>::st4(shadow + 4 * i, p0);
+        if (two) {
+            update(p1, g1, m1, v1);
+            reinterpret_cast<float4*>(param)[i2] = p1;
+            reinterpret_cast<float4*>(m)[i2] = m1;
+            reinterpret_cast<float4*>(v)[i2] = v1;
+            if (HAS_SHADOW) elem<S>::st4(shadow + 4 * i2, p1);
+        }
     }
     // tail (n not a multiple of 4)
     if (blockIdx.x == 0) {

@@ -59,11 +59,27 @@ def main():
             out = gen(emb)
         return out
 
+    try:
+        lo, hi = torch.cuda.Stream.priority_range()
+    except Exception:
+        lo, hi = 0, -1
+    LOW = max(lo, hi)
+    print("stream priority range (least, greatest):", lo, hi, flush=True)
+
+    def hi_main(reps):
+        s = torch.cuda.Stream(priority=min(lo, hi))
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            out = pipelined(reps, torch.cuda.Stream(priority=LOW))
+        torch.cuda.current_stream().wait_stream(s)
+        return out
+
     ref = sequential(1)
     torch.cuda.synchronize()
     for name, fn in (("sequential", lambda: sequential(a.reps)),
                      ("pipelined, equal priority", lambda: pipelined(a.reps, torch.cuda.Stream())),
-                     ("pipelined, encode on a low-priority stream", lambda: pipelined(a.reps, torch.cuda.Stream(priority=0))),
+                     ("pipelined, encode on the lowest-priority stream", lambda: pipelined(a.reps, torch.cuda.Stream(priority=LOW))),
+                     ("pipelined, generation on the highest-priority stream", lambda: hi_main(a.reps)),
                      ("sequential", lambda: sequential(a.reps))):
         fn(); torch.cuda.synchronize()
         t0 = time.perf_counter()
