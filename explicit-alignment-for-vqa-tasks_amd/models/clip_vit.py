@@ -169,6 +169,8 @@ class EncodeAhead:
     def submit(self, pixels: Tensor):
         main = torch.cuda.current_stream(self.vit.device)
         self.side.wait_stream(main)                      # whatever produced `pixels` (and freed the buffers the allocator may reuse)
+        if pixels.is_cuda:
+            pixels.record_stream(self.side)              # the caller may drop its reference before the side stream has read it
         with torch.cuda.stream(self.side):
             emb = self.vit.encode_image(pixels)
             done = torch.cuda.Event()
