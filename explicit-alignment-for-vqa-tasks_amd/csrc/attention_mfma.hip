@@ -242,9 +242,13 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
     for (int k0 = 0; k0 < k_end; k0 += TILE) {
         __syncthreads();                                               // the previous tile is consumed
         lstore();
-        for (int c = threadIdx.x; c < TILE; c += NT)
-            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
-        __syncthreads();
+        int keys_ok = 1;
+        for (int c = threadIdx.x; c < TILE; c += NT) {
+            const int ok = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
+            valid[c] = ok;
+            keys_ok &= ok;
+        }
+        const bool tile_all_keys = __syncthreads_and(keys_ok) != 0;    // (the barrier that publishes the tile) every key of it exists and is attended
         if (k0 + TILE < k_end) gload(k0 + TILE);
         const int nf = min(4, (min(TILE, p.Sk - k0) + 15) >> 4);      // 16-key fragments of this tile that hold a key
         if (wave_has_query) {
@@ -252,9 +256,26 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
         tile_dot<KS, SW>(st, Ks, qf, x, g, nf);
         // a full tile without a mask (every tile but the last of the CLIP tower's 257 tokens): no per-key tests, and the scale moves
         // into the exponent - exp((s - m) scale) = exp2(s c - m c'), two instructions per score instead of ten
-        const bool plain_tile = !p.causal && !p.key_mask && !p.rel_bias && k0 + TILE <= p.Sk && p.scale > 0.f;
+        // Round 4: "plain" also covers the interior tiles of masked / causal problems - every key attended (tile_all_keys) and, under a causal
+        // mask, the whole tile at or before this wave's first query (wave-uniform): the few-shot prefill's tiles below the diagonal, every
+        // full tile of the T5 encoder.  With T5's relative-position bias such a tile takes the third path below (bias added, exponent fused).
+        const bool clean_tile = tile_all_keys && (!p.causal || k0 + TILE - 1 <= q0 + wave * 16 + off) && p.scale > 0.f;
+        const bool plain_tile = clean_tile && !p.rel_bias;
+        const bool bias_tile = clean_tile && p.rel_bias;
         float m_new;
-        if (plain_tile) {
+        if (bias_tile) {
+            const float* rel = p.rel_bias + (int64_t)h * p.rel_ld;
+            const int rel_shift = p.rel_zero - (qi + off) + k0, rel_last = (int)p.rel_ld - 1;
+            float tmax = -FLT_MAX;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    st[f][r] = fmaf(st[f][r], p.scale, rel[min(max(16 * f + 4 * g + r + rel_shift, 0), rel_last)]);
+                    tmax = fmaxf(tmax, st[f][r]);
+                }
+            m_new = fmaxf(m, group4_max(tmax));
+        } else if (plain_tile) {
             float tmax = -FLT_MAX;
 #pragma unroll
             for (int f = 0; f < 4; ++f)
@@ -284,7 +305,17 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
         lsum *= corr;
 #pragma unroll
         for (int dm = 0; dm < D16; ++dm) { acc[dm][0] *= corr; acc[dm][1] *= corr; acc[dm][2] *= corr; acc[dm][3] *= corr; }
-        if (plain_tile) {
+        if (bias_tile) {
+            const float mm = m_new * 1.4426950408889634f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pj = __builtin_amdgcn_exp2f(fmaf(st[f][r], 1.4426950408889634f, -mm));
+                    st[f][r] = pj;
+                    lsum += pj;
+                }
+        } else if (plain_tile) {
             const float c2 = p.scale * 1.4426950408889634f, mm = m_new * 1.4426950408889634f;
 #pragma unroll
             for (int f = 0; f < 4; ++f)
