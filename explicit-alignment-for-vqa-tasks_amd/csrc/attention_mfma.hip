@@ -180,7 +180,9 @@ __device__ __forceinline__ bool window(Params& p, int b, int first_item, bool la
 // NW waves = 16 NW queries per workgroup: every K / V tile a workgroup stages serves 16 NW queries, so a sequence of 257 tokens
 // (ViT-L/14) is 3 workgroups of 6 waves (18 wave slots for 17 used) instead of 5 of 4 (the fifth for ONE query row), 150 prompt
 // positions 2 of 5 instead of 3 of 4: fewer staging passes over K / V for the same products (run() picks NW per problem).
-template <int KS, int D16, int NW>
+// FAST = false: the instantiation for problems of fewer than 64 keys (the training forward at S = 42: one ragged tile) - no tile of theirs can
+// take the interior-tile paths, and carrying them cost that kernel 0.6 us per launch
+template <int KS, int D16, int NW, bool FAST = true>
 __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -242,13 +244,12 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
     for (int k0 = 0; k0 < k_end; k0 += TILE) {
         __syncthreads();                                               // the previous tile is consumed
         lstore();
-        int keys_ok = 1;
-        for (int c = threadIdx.x; c < TILE; c += NT) {
-            const int ok = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
-            valid[c] = ok;
-            keys_ok &= ok;
-        }
-        const bool tile_all_keys = __syncthreads_and(keys_ok) != 0;    // (the barrier that publishes the tile) every key of it exists and is attended
+        for (int c = threadIdx.x; c < TILE; c += NT)
+            valid[c] = (k0 + c < p.Sk) && (!p.key_mask || p.key_mask[(int64_t)b * p.ld_mask + k0 + c] != 0);
+        __syncthreads();
+        // every key of the tile exists and is attended: one LDS read and a ballot per wave (TILE = 64 = the wave; a __syncthreads_and in place of
+        // the barrier cost the one-tile training forward 1.7 us per launch)
+        const bool tile_all_keys = FAST && __builtin_amdgcn_ballot_w64(valid[lane] != 0) == ~0ull;
         if (k0 + TILE < k_end) gload(k0 + TILE);
         const int nf = min(4, (min(TILE, p.Sk - k0) + 15) >> 4);      // 16-key fragments of this tile that hold a key
         if (wave_has_query) {
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(64 * NW) void fwd_kernel(Params p) {
         // Round 4: "plain" also covers the interior tiles of masked / causal problems - every key attended (tile_all_keys) and, under a causal
         // mask, the whole tile at or before this wave's first query (wave-uniform): the few-shot prefill's tiles below the diagonal, every
         // full tile of the T5 encoder.  With T5's relative-position bias such a tile takes the third path below (bias added, exponent fused).
-        const bool clean_tile = tile_all_keys && (!p.causal || k0 + TILE - 1 <= q0 + wave * 16 + off) && p.scale > 0.f;
+        const bool clean_tile = FAST && tile_all_keys && (!p.causal || k0 + TILE - 1 <= q0 + wave * 16 + off) && p.scale > 0.f;
         const bool plain_tile = clean_tile && !p.rel_bias;
         const bool bias_tile = clean_tile && p.rel_bias;
         float m_new;
@@ -974,7 +975,8 @@ int launch(int which, const Params& p, hipStream_t s) {
             }
         const dim3 grid((p.Sq + 16 * nw - 1) / (16 * nw), p.B * p.H);
         const size_t lds = 2 * row + TILE * 4;
-        if (nw == 4) hipLaunchKernelGGL((fwd_kernel<KS, D16, 4>), grid, dim3(256), lds, s, p);
+        if (nw == 4 && p.Sk < TILE) hipLaunchKernelGGL((fwd_kernel<KS, D16, 4, false>), grid, dim3(256), lds, s, p);
+        else if (nw == 4) hipLaunchKernelGGL((fwd_kernel<KS, D16, 4>), grid, dim3(256), lds, s, p);
         else if (nw == 5) hipLaunchKernelGGL((fwd_kernel<KS, D16, 5>), grid, dim3(320), lds, s, p);
         else if (nw == 6) hipLaunchKernelGGL((fwd_kernel<KS, D16, 6>), grid, dim3(384), lds, s, p);
         else hipLaunchKernelGGL((fwd_kernel<KS, D16, 8>), grid, dim3(512), lds, s, p);

@@ -35,7 +35,9 @@ struct Knobs {
                                 no_row_split(((k >> 25) & 1) != 0) {}
 };
 
-struct GemmParams {
+// GemmParamsBase is the kernel argument of the plain kernels; GemmParams (below) adds the eavqa_gemm_ln fields and is what the host code and the
+// LN instantiations pass: the plain launches carry the kernel arguments they always did (88 bytes - two cache lines - fewer than the full struct).
+struct GemmParamsBase {
     const void* A; const void* B; void* C;
     const float* bias; const void* aux_in; void* aux_out; const void* residual;   // residual: float32, or the operand dtype when res_lowp
     const float* row_scale;        // fp8 path: per-row dequantisation scale of A (multiplies alpha), else NULL
@@ -48,6 +50,8 @@ struct GemmParams {
     int tiles_m, tiles_n;
     int group_n;                   // 256 x 256 kernel: tile columns per group of the in-XCD tile order (0 = m fastest)
     int vec_c, vec_aux, vec_res, vec_bias;   // 16-byte (8-byte for bf16) vector access allowed on C / aux / residual / bias
+};
+struct GemmParams : GemmParamsBase {
     // -- eavqa_gemm_ln (LayerNorm of a frozen LM folded into its neighbours, include/eavqa.h) --
     // producer side: a second copy of the result in the operand dtype and (sum, sum of squares) of every result row per 64-column slot
     void* copy_out = nullptr; int64_t ld_copy = 0; int vec_copy = 0;
@@ -59,6 +63,11 @@ struct GemmParams {
 };
 constexpr int LN_ROWSTAT_BYTES = 2048;                 // (rstd, -rstd mean) of up to 256 tile rows, behind a kernel's ring / C tile in dynamic LDS
 inline int ln_lds(const GemmParams& p) { return p.ln_stats ? LN_ROWSTAT_BYTES : 0; }
+// kernel-side view: the full struct from either kernel argument (the LN fields of a plain launch are compile-time nulls: their code folds away)
+__device__ __forceinline__ GemmParams widen(const GemmParams& k) { return k; }
+__device__ __forceinline__ GemmParams widen(const GemmParamsBase& k) { GemmParams p; static_cast<GemmParamsBase&>(p) = k; return p; }
+template <bool LNX> struct KernArg { using type = GemmParamsBase; };
+template <> struct KernArg<true> { using type = GemmParams; };
 
 constexpr int BM = 128, BN = 128;
 constexpr int CS_PITCH = 132;                       // floats per row of the staged C tile
@@ -966,7 +975,8 @@ __device__ __forceinline__ bool big_tile(const GemmParams& p, int gx, int gy, in
 }
 
 template <bool LNX>
-__global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(1024) void gemm_bf16_big_kernel(typename KernArg<LNX>::type pk, int gx, int gy, int tiles_m, int tiles_n) {
+    const GemmParams p = widen(pk);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
     if (!big_tile(p, gx, gy, tiles_m, tiles_n, tm, tn)) return;

@@ -17,7 +17,8 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 template <int WM, int WN, int MF, int NF, int NST, int LW, bool DB>
-__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_fp8_k128s_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_fp8_k128s_kernel(GemmParamsBase pk, int gx, int gy, int tiles_m, int tiles_n) {
+    const GemmParams p = widen(pk);
     using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;

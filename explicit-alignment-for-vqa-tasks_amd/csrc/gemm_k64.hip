@@ -145,7 +145,8 @@ __device__ __forceinline__ void k64s_store_tile(const GemmParams& p, const f32x4
 
 // LNX: the eavqa_gemm_ln form (its own instantiation: the plain kernels stay what they were, instruction for instruction)
 template <int WM, int WN, int MF, int NF, int NST, int LW, bool LNX>
-__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(GemmParams p, int gx, int gy, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(64 * (WM * WN + LW)) void gemm_bf16_k64s_kernel(typename KernArg<LNX>::type pk, int gx, int gy, int tiles_m, int tiles_n) {
+    const GemmParams p = widen(pk);
     using G = K64SGeo<WM, WN, MF, NF, NST, LW>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int tm, tn;
